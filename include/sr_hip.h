@@ -1,0 +1,221 @@
+/*
+ * sr_hip.h -- C ABI of the MI355X-native tile -> blend -> assess engine (libsrhip.so).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch / numpy types.  Each entry
+ * point names the reference interface it replaces (paths relative to the reference repo).
+ * Host-side mirrors of the reference's Python classes (tiling_module.TilingModule,
+ * blending_module.BlendingModule, quality_assessment_module.QualityAssessmentModule,
+ * main.SuperResolutionPipeline) bind these through ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *  - every function returns an int status (SR_OK == 0, negative = error); the message of the
+ *    last error on the calling thread is sr_last_error().
+ *  - "d_" pointers are device (HBM) addresses on the context's GPU, "h_" pointers are host.
+ *    Small descriptor arrays (tile rectangles etc.) are always host pointers.
+ *  - images are row-major, channel-interleaved (HWC) exactly like the reference's ndarrays;
+ *    strides are in BYTES.
+ *  - all device work is enqueued on the context's stream (sr_ctx_create makes one;
+ *    sr_ctx_create_on_stream adopts the caller's, e.g. torch's current stream).  Functions
+ *    that return a value to the host synchronise that stream; the others do not.
+ *  - a context may be used from several threads: calls on one context are serialised by an
+ *    internal mutex (the reference's ParallelBlender calls laplacian_fusion from a thread
+ *    pool on one object, blending_module.py:1668-1701).
+ *  - the library never keeps a host pointer after a call returns.
+ */
+#ifndef SR_HIP_H
+#define SR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SR_API __attribute__((visibility("default")))
+
+enum sr_status {
+    SR_OK = 0,
+    SR_ERR_INVALID_ARG = -1, /* -> ValueError in the Python mirror                    */
+    SR_ERR_SHAPE = -2,       /* shape / size mismatch (cv2.error in the reference)    */
+    SR_ERR_OOM = -3,
+    SR_ERR_HIP = -4,         /* any HIP runtime failure, incl. "no device"            */
+    SR_ERR_COMM = -5,
+    SR_ERR_UNSUPPORTED = -6
+};
+
+/* tiling_module.PaddingMode (tiling_module.py:40-45) */
+enum sr_pad_mode { SR_PAD_MIRROR = 0, SR_PAD_REPLICATE = 1, SR_PAD_REFLECT = 2, SR_PAD_CONSTANT = 3 };
+/* blending_module.WeightType (blending_module.py:52-56) */
+enum sr_weight_type { SR_W_LINEAR = 0, SR_W_COSINE = 1, SR_W_SIGMOID = 2 };
+/* calculate_ssim branches (quality_assessment_module.py:365-417) */
+enum sr_ssim_mode { SR_SSIM_UNIFORM7 = 0, SR_SSIM_GAUSS11 = 1, SR_SSIM_SIMPLE = 2 };
+enum sr_dtype { SR_U8 = 0, SR_F32 = 1 };
+
+typedef struct sr_ctx sr_ctx;
+typedef struct sr_blend_plan sr_blend_plan;
+
+/* ---- library / context ------------------------------------------------------------- */
+SR_API int sr_version(void);
+SR_API const char *sr_last_error(void);
+SR_API int sr_device_count(int *count);
+SR_API int sr_ctx_create(int device_id, sr_ctx **out);
+SR_API int sr_ctx_create_on_stream(int device_id, void *hip_stream, sr_ctx **out);
+SR_API int sr_ctx_destroy(sr_ctx *ctx);
+SR_API int sr_ctx_sync(sr_ctx *ctx);
+
+/* device memory helpers, so a host language needs no HIP binding of its own */
+SR_API int sr_dev_alloc(sr_ctx *ctx, size_t bytes, void **d_ptr);
+SR_API int sr_dev_free(sr_ctx *ctx, void *d_ptr);
+SR_API int sr_memcpy_h2d(sr_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+SR_API int sr_memcpy_d2h(sr_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+SR_API int sr_memcpy_d2d(sr_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
+SR_API int sr_memset_d(sr_ctx *ctx, void *d_dst, int value, size_t bytes);
+
+/* per-kernel HIP-event timing on the context's stream (bench.py's roofline leg).
+ * sr_prof_get: copies up to cap records; name is the kernel family, ms the summed time,
+ * launches the number of launches since the last sr_prof_reset. */
+typedef struct sr_prof_record {
+    char name[48];
+    double ms;
+    int64_t launches;
+} sr_prof_record;
+SR_API int sr_prof_enable(sr_ctx *ctx, int on);
+SR_API int sr_prof_reset(sr_ctx *ctx);
+SR_API int sr_prof_get(sr_ctx *ctx, sr_prof_record *h_records, int cap, int *n);
+
+/* ---- host-only bookkeeping (bit-exact integer restatements; no GPU needed) ----------- */
+/* TilingModule._calculate_tile_positions (tiling_module.py:572-608).
+ * h_xywh receives n_tiles x (x, y, w, h), row-major over the grid; *n_tiles is always set,
+ * SR_ERR_SHAPE if cap is too small. */
+SR_API int sr_tile_plan(int image_w, int image_h, int block_size, int overlap_px, int *n_tiles,
+                        int *h_xywh, int cap);
+/* TilingModule._calculate_overlap_for_tile (tiling_module.py:610-646): -> top,bottom,left,right */
+SR_API int sr_tile_overlaps(int x, int y, int w, int h, int image_w, int image_h, int block_size,
+                            int overlap_px, int *h_tblr);
+/* TilingModule._build_neighbor_relationships (tiling_module.py:786-823):
+ * h_nbr receives n x (top, bottom, left, right) tile indices, -1 where absent. */
+SR_API int sr_tile_neighbors(const int *h_xywh, int n, int block_size, int overlap_px, int *h_nbr);
+/* SuperResolutionPipeline._calculate_target_size presets (main.py:168-184); preset_mp in
+ * {100,150,200}. */
+SR_API int sr_target_size(int width, int height, int preset_mp, int *out_w, int *out_h);
+/* BlendingModule._create_distance_weight_map (blending_module.py:529-561) tabulated by integer
+ * edge distance d = 0..fw: W[y][x] = lut[min(d(y,x), fw)].  h_lut holds fw+1 floats. */
+SR_API int sr_weight_lut(int fw, int weight_type, float *h_lut);
+
+/* ---- tile extract (tiling_module.py:713-724 slice + _apply_padding :522-570) ---------- */
+/* Copies n tiles out of one HWC u8 image into n contiguous block x block x cn tiles, padding
+ * the bottom/right of edge tiles with the reference's border rule. */
+SR_API int sr_tile_extract_pad(sr_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, int cn,
+                               int64_t img_stride, const int *h_xywh, int n, int block_size,
+                               int pad_mode, uint8_t *d_tiles);
+/* Plain overlap-tile extract (no padding): tile i = img[y:y+h, x:x+w] into d_tiles[i] with row
+ * stride tile_strides[i]; used by the benchmark's output-space tile stage. */
+SR_API int sr_tile_extract(sr_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, int cn,
+                           int64_t img_stride, const int *h_xywh, int n, void *const *h_d_tiles,
+                           const int64_t *h_tile_strides);
+
+/* ---- pyramid primitives (BlendingModule.build_gaussian_pyramid :217-269 -> cv2.pyrDown;
+ *      build_laplacian_pyramid / collapse :271-363 -> cv2.pyrUp), fp32 HWC, dense ------- */
+SR_API int sr_pyr_down(sr_ctx *ctx, const float *d_src, int h, int w, int cn, float *d_dst);
+SR_API int sr_pyr_up(sr_ctx *ctx, const float *d_src, int hs, int ws, int cn, float *d_dst, int hd,
+                     int wd);
+/* d_out = d_a - pyrUp(d_b) (one Laplacian level) and d_out = pyrUp(d_b) + d_a (one collapse step) */
+SR_API int sr_pyr_up_sub(sr_ctx *ctx, const float *d_a, int h, int w, int cn, const float *d_b,
+                         float *d_out);
+SR_API int sr_pyr_up_add(sr_ctx *ctx, const float *d_a, int h, int w, int cn, const float *d_b,
+                         float *d_out);
+
+/* ---- blends (BlendingModule.laplacian_fusion :369-506, weighted_average_fusion :661-760) */
+typedef struct sr_tile_rect {
+    int x, y; /* canvas position of the tile's top-left pixel (TileInfo.x, TileInfo.y) */
+    int w, h; /* tile size in pixels                                                   */
+} sr_tile_rect;
+
+/* A plan owns the device workspace (per-tile Gaussian / collapsed pyramids, weight pyramids and
+ * descriptor tables) for one tile arrangement.  Only canvas rows [row_begin, row_end) are
+ * produced (0, canvas_h for the whole image): a strip owner in the multi-GPU blend gets
+ * bit-identical rows because every pyramid value it needs is computed from the same inputs in
+ * the same order. */
+SR_API int sr_blend_plan_create(sr_ctx *ctx, const sr_tile_rect *h_tiles, int n, int cn, int canvas_h,
+                                int canvas_w, int levels, int weight_type, int row_begin,
+                                int row_end, sr_blend_plan **out);
+SR_API int sr_blend_plan_destroy(sr_blend_plan *plan);
+/* tile-local rows [*r0, *r1) of tile t that the plan reads (empty if r0 >= r1): what a strip
+ * owner must hold / receive for that tile. */
+SR_API int sr_blend_plan_tile_rows(const sr_blend_plan *plan, int t, int *r0, int *r1);
+SR_API int sr_blend_plan_workspace_bytes(const sr_blend_plan *plan, size_t *bytes);
+
+/* h_d_tiles[i]: device address of row 0 of tile i (rows outside sr_blend_plan_tile_rows are
+ * never touched, so the address may be virtual); h_strides[i]: row stride in bytes.
+ * d_canvas: u8 HWC canvas (row stride canvas_stride bytes), only rows [row_begin,row_end)
+ * are written.  d_canvas_f32 (nullable): dense fp32 HWC canvas receiving the normalised value
+ * before clip / truncation (parity tests). */
+SR_API int sr_laplacian_blend(sr_blend_plan *plan, int dtype, void *const *h_d_tiles,
+                              const int64_t *h_strides, uint8_t *d_canvas, int64_t canvas_stride,
+                              float *d_canvas_f32);
+SR_API int sr_weighted_blend(sr_blend_plan *plan, int dtype, void *const *h_d_tiles,
+                             const int64_t *h_strides, uint8_t *d_canvas, int64_t canvas_stride,
+                             float *d_canvas_f32);
+
+/* Host-buffer conveniences with the reference's call shape (ndarrays in, ndarray out):
+ * stage tiles to HBM, blend, copy the canvas back.  h_tiles[i] is a dense HWC array. */
+SR_API int sr_laplacian_fusion_host(sr_ctx *ctx, int dtype, const void *const *h_tiles,
+                                    const sr_tile_rect *h_rects, int n, int cn, int canvas_h,
+                                    int canvas_w, int levels, int weight_type, uint8_t *h_canvas,
+                                    float *h_canvas_f32);
+SR_API int sr_weighted_fusion_host(sr_ctx *ctx, int dtype, const void *const *h_tiles,
+                                   const sr_tile_rect *h_rects, int n, int cn, int canvas_h,
+                                   int canvas_w, int weight_type, uint8_t *h_canvas,
+                                   float *h_canvas_f32);
+
+/* ---- TilingModule.merge_tiles feather path (tiling_module.py:1074-1175) ---------------- */
+typedef struct sr_merge_tile {
+    int x, y;                 /* int(global_x*scale), int(global_y*scale)                 */
+    int src_w, src_h;         /* size of the tile data as handed in                       */
+    int out_w, out_h;         /* metadata.output_w/h: data is bilinearly resized to this  */
+    int ov_t, ov_b, ov_l, ov_r; /* int(overlap*scale) ramps; 0 = none                     */
+} sr_merge_tile;
+SR_API int sr_feather_merge(sr_ctx *ctx, const sr_merge_tile *h_tiles, int n, void *const *h_d_tiles,
+                            const int64_t *h_strides, int blending, uint8_t *d_canvas,
+                            int64_t canvas_stride, int canvas_h, int canvas_w);
+
+/* ---- quality metrics (quality_assessment_module.py:277-417) ---------------------------- */
+/* Sum of squared differences over h rows of rowlen u8 elements -> *h_sse (exact integer).
+ * PSNR = 10 log10(data_range^2 / (sse / (h*rowlen))) is finished on the host (and partial sums
+ * of strips are simply added). */
+SR_API int sr_sse_u8(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uint8_t *d_b,
+                     int64_t stride_b, int h, int64_t rowlen, uint64_t *h_sse);
+/* Asynchronous form: result left in device memory (8 bytes), no stream sync. */
+SR_API int sr_sse_u8_async(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uint8_t *d_b,
+                           int64_t stride_b, int h, int64_t rowlen, uint64_t *d_sse);
+SR_API double sr_psnr_from_sse(uint64_t sse, uint64_t count, double data_range);
+
+/* SSIM between two u8 images of h x w pixels with cn channels (cn == 3: RGB -> gray with the
+ * OpenCV fixed-point rule, gray_shift 15 or 14; cn == 1: already gray).  The SSIM map is
+ * summed over map rows [row_begin,row_end) intersected with the mode's valid region; the sum
+ * and the number of map samples come back so strips can be added.  mean = sum / count. */
+SR_API int sr_ssim_u8(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uint8_t *d_b,
+                      int64_t stride_b, int h, int w, int cn, int mode, int gray_shift,
+                      double data_range, int row_begin, int row_end, double *h_sum,
+                      uint64_t *h_count);
+SR_API int sr_ssim_u8_async(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uint8_t *d_b,
+                            int64_t stride_b, int h, int w, int cn, int mode, int gray_shift,
+                            double data_range, int row_begin, int row_end, double *d_sum,
+                            uint64_t *h_count);
+/* cv2.cvtColor(RGB2GRAY) on u8 (quality_assessment_module.py:359-360) */
+SR_API int sr_rgb2gray_u8(sr_ctx *ctx, const uint8_t *d_rgb, int64_t stride, int h, int w,
+                          int gray_shift, uint8_t *d_gray, int64_t gray_stride);
+/* cv2.resize(..., INTER_CUBIC) on u8 (downsample_bicubic :226-253; also the benchmark's SR stub) */
+SR_API int sr_resize_cubic_u8(sr_ctx *ctx, const uint8_t *d_src, int64_t src_stride, int h, int w,
+                              int cn, uint8_t *d_dst, int64_t dst_stride, int dh, int dw);
+/* Same sampling, but only the dst window [x0,x0+ww) x [y0,y0+wh) of the virtual dh x dw result is
+ * produced (dense, stride dst_stride): the SR stub's per-tile form. */
+SR_API int sr_resize_cubic_window_u8(sr_ctx *ctx, const uint8_t *d_src, int64_t src_stride, int h,
+                                     int w, int cn, int dh, int dw, int x0, int y0, int ww, int wh,
+                                     uint8_t *d_dst, int64_t dst_stride);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SR_HIP_H */

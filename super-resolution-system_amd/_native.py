@@ -1,0 +1,450 @@
+"""ctypes binding of include/sr_hip.h (libsrhip.so) -- the only way the Python host code
+reaches the GPU.  There is deliberately no CPU fallback: if the library or a device is missing,
+the compute entry points raise (SrNativeError), they never route through oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsrhip.so")
+
+SR_OK = 0
+SR_ERR_INVALID_ARG, SR_ERR_SHAPE, SR_ERR_OOM, SR_ERR_HIP, SR_ERR_COMM, SR_ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6
+PAD_MODES = {"mirror": 0, "replicate": 1, "reflect": 2, "constant": 3}
+WEIGHT_TYPES = {"linear": 0, "cosine": 1, "sigmoid": 2}
+SSIM_MODES = {"uniform": 0, "gauss": 1, "simple": 2}
+SR_U8, SR_F32 = 0, 1
+
+
+class SrNativeError(RuntimeError):
+    """HIP / library failure (SR_ERR_HIP, SR_ERR_OOM, SR_ERR_COMM, SR_ERR_UNSUPPORTED)."""
+
+
+class SrShapeError(ValueError):
+    """SR_ERR_SHAPE: the reference raises cv2.error / ValueError for these."""
+
+
+class TileRect(C.Structure):
+    _fields_ = [("x", C.c_int), ("y", C.c_int), ("w", C.c_int), ("h", C.c_int)]
+
+
+class MergeTile(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("x", "y", "src_w", "src_h", "out_w", "out_h",
+                                        "ov_t", "ov_b", "ov_l", "ov_r")]
+
+
+class ProfRecord(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("ms", C.c_double), ("launches", C.c_int64)]
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+# name -> (restype, argtypes); every symbol include/sr_hip.h declares
+_vp, _i, _i64, _sz, _dbl = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_double
+_pi = C.POINTER(C.c_int)
+SIGNATURES = {
+    "sr_version": (_i, []),
+    "sr_last_error": (C.c_char_p, []),
+    "sr_device_count": (_i, [_pi]),
+    "sr_ctx_create": (_i, [_i, C.POINTER(_vp)]),
+    "sr_ctx_create_on_stream": (_i, [_i, _vp, C.POINTER(_vp)]),
+    "sr_ctx_destroy": (_i, [_vp]),
+    "sr_ctx_sync": (_i, [_vp]),
+    "sr_dev_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "sr_dev_free": (_i, [_vp, _vp]),
+    "sr_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
+    "sr_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
+    "sr_memcpy_d2d": (_i, [_vp, _vp, _vp, _sz]),
+    "sr_memset_d": (_i, [_vp, _vp, _i, _sz]),
+    "sr_prof_enable": (_i, [_vp, _i]),
+    "sr_prof_reset": (_i, [_vp]),
+    "sr_prof_get": (_i, [_vp, C.POINTER(ProfRecord), _i, _pi]),
+    "sr_tile_plan": (_i, [_i, _i, _i, _i, _pi, _pi, _i]),
+    "sr_tile_overlaps": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _pi]),
+    "sr_tile_neighbors": (_i, [_pi, _i, _i, _i, _pi]),
+    "sr_target_size": (_i, [_i, _i, _i, _pi, _pi]),
+    "sr_weight_lut": (_i, [_i, _i, C.POINTER(C.c_float)]),
+    "sr_tile_extract_pad": (_i, [_vp, _vp, _i, _i, _i, _i64, _pi, _i, _i, _i, _vp]),
+    "sr_tile_extract": (_i, [_vp, _vp, _i, _i, _i, _i64, _pi, _i, C.POINTER(_vp), C.POINTER(_i64)]),
+    "sr_pyr_down": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "sr_pyr_up": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i]),
+    "sr_pyr_up_sub": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "sr_pyr_up_add": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "sr_blend_plan_create": (_i, [_vp, C.POINTER(TileRect), _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "sr_blend_plan_destroy": (_i, [_vp]),
+    "sr_blend_plan_tile_rows": (_i, [_vp, _i, _pi, _pi]),
+    "sr_blend_plan_workspace_bytes": (_i, [_vp, C.POINTER(_sz)]),
+    "sr_laplacian_blend": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_i64), _vp, _i64, _vp]),
+    "sr_weighted_blend": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_i64), _vp, _i64, _vp]),
+    "sr_laplacian_fusion_host": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(TileRect), _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "sr_weighted_fusion_host": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(TileRect), _i, _i, _i, _i, _i, _vp, _vp]),
+    "sr_feather_merge": (_i, [_vp, C.POINTER(MergeTile), _i, C.POINTER(_vp), C.POINTER(_i64), _i, _vp, _i64, _i, _i]),
+    "sr_sse_u8": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i64, C.POINTER(C.c_uint64)]),
+    "sr_sse_u8_async": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i64, _vp]),
+    "sr_psnr_from_sse": (_dbl, [C.c_uint64, C.c_uint64, _dbl]),
+    "sr_ssim_u8": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _dbl, _i, _i, C.POINTER(_dbl), C.POINTER(C.c_uint64)]),
+    "sr_ssim_u8_async": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _dbl, _i, _i, _vp, C.POINTER(C.c_uint64)]),
+    "sr_rgb2gray_u8": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _i64]),
+    "sr_resize_cubic_u8": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _i64, _i, _i]),
+    "sr_resize_cubic_window_u8": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64]),
+}
+
+
+def load():
+    """Load libsrhip.so (building it first if the sources are newer).  Raises SrNativeError."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            try:
+                from _build import build_native  # type: ignore
+            except ImportError:
+                import importlib.util
+                spec = importlib.util.spec_from_file_location("_sr_build", os.path.join(_HERE, "_build.py"))
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                build_native = mod.build_native
+            try:
+                build_native()
+            except Exception as exc:  # noqa: BLE001
+                raise SrNativeError(f"libsrhip.so is missing and could not be built: {exc}") from exc
+        try:
+            lib = C.CDLL(LIB_PATH)
+        except OSError as exc:
+            raise SrNativeError(f"cannot load {LIB_PATH}: {exc}") from exc
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def last_error() -> str:
+    return load().sr_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int) -> None:
+    if rc == SR_OK:
+        return
+    msg = last_error()
+    if rc == SR_ERR_INVALID_ARG:
+        raise ValueError(msg)
+    if rc == SR_ERR_SHAPE:
+        raise SrShapeError(msg)
+    if rc == SR_ERR_OOM:
+        raise MemoryError(msg)
+    raise SrNativeError(f"[sr {rc}] {msg}")
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = load().sr_device_count(C.byref(n))
+    return n.value if rc == SR_OK else 0
+
+
+# ------------------------------------------------------------------------------------------
+# host-only bookkeeping wrappers
+# ------------------------------------------------------------------------------------------
+def tile_plan(image_w: int, image_h: int, block: int, overlap_px: int) -> List[Tuple[int, int, int, int]]:
+    lib = load()
+    n = C.c_int(0)
+    check(lib.sr_tile_plan(image_w, image_h, block, overlap_px, C.byref(n), None, 0))
+    buf = (C.c_int * (4 * n.value))()
+    check(lib.sr_tile_plan(image_w, image_h, block, overlap_px, C.byref(n), buf, n.value))
+    return [tuple(buf[4 * i: 4 * i + 4]) for i in range(n.value)]
+
+
+def tile_overlaps(x, y, w, h, image_w, image_h, block, overlap_px) -> Tuple[int, int, int, int]:
+    out = (C.c_int * 4)()
+    check(load().sr_tile_overlaps(x, y, w, h, image_w, image_h, block, overlap_px, out))
+    return tuple(out)
+
+
+def tile_neighbors(xywh: Sequence[Tuple[int, int, int, int]], block: int, overlap_px: int):
+    n = len(xywh)
+    flat = (C.c_int * (4 * n))(*[v for t in xywh for v in t])
+    out = (C.c_int * (4 * n))()
+    check(load().sr_tile_neighbors(flat, n, block, overlap_px, out))
+    return [tuple(out[4 * i: 4 * i + 4]) for i in range(n)]
+
+
+def target_size(width: int, height: int, preset_mp: int) -> Tuple[int, int]:
+    w, h = C.c_int(0), C.c_int(0)
+    check(load().sr_target_size(width, height, preset_mp, C.byref(w), C.byref(h)))
+    return w.value, h.value
+
+
+def weight_lut(fw: int, weight_type: str) -> np.ndarray:
+    out = np.empty(fw + 1, dtype=np.float32)
+    check(load().sr_weight_lut(fw, WEIGHT_TYPES[weight_type], out.ctypes.data_as(C.POINTER(C.c_float))))
+    return out
+
+
+def psnr_from_sse(sse: int, count: int, data_range: float = 255.0) -> float:
+    return float(load().sr_psnr_from_sse(C.c_uint64(sse), C.c_uint64(count), data_range))
+
+
+# ------------------------------------------------------------------------------------------
+# device context
+# ------------------------------------------------------------------------------------------
+class DeviceBuffer:
+    """Owned HBM allocation."""
+
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(ctx.lib.sr_dev_alloc(ctx.handle, max(self.nbytes, 1), C.byref(p)))
+        self.ptr = p.value
+
+    def free(self):
+        if self.ptr and self.ctx.handle:
+            self.ctx.lib.sr_dev_free(self.ctx.handle, C.c_void_p(self.ptr))
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class Context:
+    """One GPU + one stream (sr_ctx).  Thread-compatible: calls are serialised inside the library."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self.lib = load()
+        h = C.c_void_p()
+        if stream is None:
+            check(self.lib.sr_ctx_create(int(device), C.byref(h)))
+        else:
+            check(self.lib.sr_ctx_create_on_stream(int(device), C.c_void_p(stream), C.byref(h)))
+        self.handle = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.sr_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def sync(self):
+        check(self.lib.sr_ctx_sync(self.handle))
+
+    # memory ---------------------------------------------------------------------------
+    def alloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    def upload(self, arr: np.ndarray) -> DeviceBuffer:
+        arr = np.ascontiguousarray(arr)
+        buf = DeviceBuffer(self, arr.nbytes)
+        check(self.lib.sr_memcpy_h2d(self.handle, C.c_void_p(buf.ptr), arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+        return buf
+
+    def download(self, ptr: int, shape, dtype) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        check(self.lib.sr_memcpy_d2h(self.handle, out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), out.nbytes))
+        return out
+
+    def memset(self, ptr: int, value: int, nbytes: int):
+        check(self.lib.sr_memset_d(self.handle, C.c_void_p(ptr), value, nbytes))
+
+    # profiling ------------------------------------------------------------------------
+    def prof_enable(self, on: bool = True):
+        check(self.lib.sr_prof_enable(self.handle, 1 if on else 0))
+
+    def prof_reset(self):
+        check(self.lib.sr_prof_reset(self.handle))
+
+    def prof_get(self):
+        n = C.c_int(0)
+        recs = (ProfRecord * 64)()
+        check(self.lib.sr_prof_get(self.handle, recs, 64, C.byref(n)))
+        return {recs[i].name.decode(): (recs[i].ms, recs[i].launches) for i in range(min(n.value, 64))}
+
+    # device-pointer ops ------------------------------------------------------------------
+    def tile_extract_pad(self, d_img: int, img_h, img_w, cn, img_stride, xywh, block, pad_mode: str, d_tiles: int):
+        n = len(xywh)
+        flat = (C.c_int * (4 * n))(*[int(v) for t in xywh for v in t])
+        check(self.lib.sr_tile_extract_pad(self.handle, C.c_void_p(d_img), img_h, img_w, cn, img_stride, flat, n,
+                                           block, PAD_MODES[pad_mode], C.c_void_p(d_tiles)))
+
+    def tile_extract(self, d_img: int, img_h, img_w, cn, img_stride, xywh, d_tiles: Sequence[int],
+                     strides: Sequence[int]):
+        n = len(xywh)
+        flat = (C.c_int * (4 * n))(*[int(v) for t in xywh for v in t])
+        ptrs = (C.c_void_p * n)(*[C.c_void_p(p) for p in d_tiles])
+        st = (C.c_int64 * n)(*[int(s) for s in strides])
+        check(self.lib.sr_tile_extract(self.handle, C.c_void_p(d_img), img_h, img_w, cn, img_stride, flat, n, ptrs, st))
+
+    def sse_u8(self, d_a: int, stride_a: int, d_b: int, stride_b: int, h: int, rowlen: int) -> int:
+        out = C.c_uint64(0)
+        check(self.lib.sr_sse_u8(self.handle, C.c_void_p(d_a), stride_a, C.c_void_p(d_b), stride_b, h, rowlen,
+                                 C.byref(out)))
+        return out.value
+
+    def sse_u8_async(self, d_a, stride_a, d_b, stride_b, h, rowlen, d_out: int):
+        check(self.lib.sr_sse_u8_async(self.handle, C.c_void_p(d_a), stride_a, C.c_void_p(d_b), stride_b, h, rowlen,
+                                       C.c_void_p(d_out)))
+
+    def ssim_u8(self, d_a, stride_a, d_b, stride_b, h, w, cn, mode: str, gray_shift=15, data_range=255.0,
+                row_begin=0, row_end=None) -> Tuple[float, int]:
+        s, n = C.c_double(0.0), C.c_uint64(0)
+        check(self.lib.sr_ssim_u8(self.handle, C.c_void_p(d_a), stride_a, C.c_void_p(d_b), stride_b, h, w, cn,
+                                  SSIM_MODES[mode], gray_shift, data_range, row_begin,
+                                  h if row_end is None else row_end, C.byref(s), C.byref(n)))
+        return s.value, n.value
+
+    def ssim_u8_async(self, d_a, stride_a, d_b, stride_b, h, w, cn, mode: str, d_sum: int, gray_shift=15,
+                      data_range=255.0, row_begin=0, row_end=None) -> int:
+        n = C.c_uint64(0)
+        check(self.lib.sr_ssim_u8_async(self.handle, C.c_void_p(d_a), stride_a, C.c_void_p(d_b), stride_b, h, w, cn,
+                                        SSIM_MODES[mode], gray_shift, data_range, row_begin,
+                                        h if row_end is None else row_end, C.c_void_p(d_sum), C.byref(n)))
+        return n.value
+
+    def rgb2gray_u8(self, d_rgb, stride, h, w, d_gray, gray_stride, gray_shift=15):
+        check(self.lib.sr_rgb2gray_u8(self.handle, C.c_void_p(d_rgb), stride, h, w, gray_shift, C.c_void_p(d_gray),
+                                      gray_stride))
+
+    def resize_cubic_u8(self, d_src, src_stride, h, w, cn, d_dst, dst_stride, dh, dw):
+        check(self.lib.sr_resize_cubic_u8(self.handle, C.c_void_p(d_src), src_stride, h, w, cn, C.c_void_p(d_dst),
+                                          dst_stride, dh, dw))
+
+    def resize_cubic_window_u8(self, d_src, src_stride, h, w, cn, dh, dw, x0, y0, ww, wh, d_dst, dst_stride):
+        check(self.lib.sr_resize_cubic_window_u8(self.handle, C.c_void_p(d_src), src_stride, h, w, cn, dh, dw, x0, y0,
+                                                 ww, wh, C.c_void_p(d_dst), dst_stride))
+
+    # numpy-in / numpy-out conveniences (stage through HBM) ----------------------------------
+    def pyr_down_np(self, img: np.ndarray) -> np.ndarray:
+        a = np.ascontiguousarray(img, dtype=np.float32)
+        h, w = a.shape[:2]
+        cn = a.shape[2] if a.ndim == 3 else 1
+        out_shape = ((h + 1) // 2, (w + 1) // 2) + a.shape[2:]
+        src = self.upload(a)
+        dst = self.alloc(int(np.prod(out_shape)) * 4)
+        check(self.lib.sr_pyr_down(self.handle, C.c_void_p(src.ptr), h, w, cn, C.c_void_p(dst.ptr)))
+        res = self.download(dst.ptr, out_shape, np.float32)
+        src.free(); dst.free()
+        return res
+
+    def pyr_up_np(self, img: np.ndarray, dst_hw, a: Optional[np.ndarray] = None, mode: str = "up") -> np.ndarray:
+        """mode 'up': pyrUp(img); 'sub': a - pyrUp(img); 'add': pyrUp(img) + a."""
+        s = np.ascontiguousarray(img, dtype=np.float32)
+        hs, ws = s.shape[:2]
+        cn = s.shape[2] if s.ndim == 3 else 1
+        hd, wd = int(dst_hw[0]), int(dst_hw[1])
+        out_shape = (hd, wd) + s.shape[2:]
+        src = self.upload(s)
+        dst = self.alloc(int(np.prod(out_shape)) * 4)
+        if mode == "up":
+            check(self.lib.sr_pyr_up(self.handle, C.c_void_p(src.ptr), hs, ws, cn, C.c_void_p(dst.ptr), hd, wd))
+        else:
+            if (hs, ws) != ((hd + 1) // 2, (wd + 1) // 2):
+                raise SrShapeError(f"pyrUp: source {hs}x{ws} does not match destination {hd}x{wd}")
+            aa = self.upload(np.ascontiguousarray(a, dtype=np.float32))
+            fn = self.lib.sr_pyr_up_sub if mode == "sub" else self.lib.sr_pyr_up_add
+            check(fn(self.handle, C.c_void_p(aa.ptr), hd, wd, cn, C.c_void_p(src.ptr), C.c_void_p(dst.ptr)))
+            aa.free()
+        res = self.download(dst.ptr, out_shape, np.float32)
+        src.free(); dst.free()
+        return res
+
+    def fusion_np(self, tiles: Sequence[np.ndarray], positions_yx, output_shape, levels: int, weight_type: str,
+                  laplacian: bool = True, return_float: bool = False):
+        """tiles: list of HWC (or HW) arrays, all u8 or all float; positions (y, x)."""
+        n = len(tiles)
+        is_u8 = all(t.dtype == np.uint8 for t in tiles)
+        arrs = [np.ascontiguousarray(t if is_u8 else t.astype(np.float32)) for t in tiles]
+        cn = arrs[0].shape[2] if arrs[0].ndim == 3 else 1
+        H, W = int(output_shape[0]), int(output_shape[1])
+        rects = (TileRect * n)(*[TileRect(int(p[1]), int(p[0]), a.shape[1], a.shape[0])
+                                 for a, p in zip(arrs, positions_yx)])
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        out = np.empty((H, W) if cn == 1 else (H, W, cn), dtype=np.uint8)
+        outf = np.empty(out.shape, dtype=np.float32) if return_float else None
+        fptr = outf.ctypes.data_as(C.c_void_p) if outf is not None else None
+        dt = SR_U8 if is_u8 else SR_F32
+        if laplacian:
+            check(self.lib.sr_laplacian_fusion_host(self.handle, dt, ptrs, rects, n, cn, H, W, int(levels),
+                                                    WEIGHT_TYPES[weight_type], out.ctypes.data_as(C.c_void_p), fptr))
+        else:
+            check(self.lib.sr_weighted_fusion_host(self.handle, dt, ptrs, rects, n, cn, H, W,
+                                                   WEIGHT_TYPES[weight_type], out.ctypes.data_as(C.c_void_p), fptr))
+        return (out, outf) if return_float else out
+
+
+class BlendPlan:
+    """sr_blend_plan: device workspace for one tile arrangement (optionally one canvas strip)."""
+
+    def __init__(self, ctx: Context, rects_xywh: Sequence[Tuple[int, int, int, int]], cn: int, canvas_h: int,
+                 canvas_w: int, levels: int = 6, weight_type: str = "cosine", row_begin: int = 0,
+                 row_end: Optional[int] = None):
+        self.ctx = ctx
+        self.n = len(rects_xywh)
+        self.cn = cn
+        self.canvas_h, self.canvas_w = int(canvas_h), int(canvas_w)
+        self.row_begin = int(row_begin)
+        self.row_end = int(canvas_h if row_end is None else row_end)
+        rects = (TileRect * self.n)(*[TileRect(int(x), int(y), int(w), int(h)) for (x, y, w, h) in rects_xywh])
+        h = C.c_void_p()
+        check(ctx.lib.sr_blend_plan_create(ctx.handle, rects, self.n, cn, self.canvas_h, self.canvas_w, int(levels),
+                                           WEIGHT_TYPES[weight_type], self.row_begin, self.row_end, C.byref(h)))
+        self.handle = h
+
+    def tile_rows(self, t: int) -> Tuple[int, int]:
+        a, b = C.c_int(0), C.c_int(0)
+        check(self.ctx.lib.sr_blend_plan_tile_rows(self.handle, t, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def workspace_bytes(self) -> int:
+        b = C.c_size_t(0)
+        check(self.ctx.lib.sr_blend_plan_workspace_bytes(self.handle, C.byref(b)))
+        return b.value
+
+    def blend(self, d_tiles: Sequence[int], strides: Sequence[int], d_canvas: int, canvas_stride: int,
+              dtype: int = SR_U8, d_canvas_f32: Optional[int] = None, laplacian: bool = True):
+        ptrs = (C.c_void_p * self.n)(*[C.c_void_p(p) for p in d_tiles])
+        st = (C.c_int64 * self.n)(*[int(s) for s in strides])
+        fn = self.ctx.lib.sr_laplacian_blend if laplacian else self.ctx.lib.sr_weighted_blend
+        check(fn(self.handle, dtype, ptrs, st, C.c_void_p(d_canvas), int(canvas_stride),
+                 C.c_void_p(d_canvas_f32) if d_canvas_f32 else None))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.ctx.lib.sr_blend_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+_default_ctx = {}
+_default_lock = threading.Lock()
+
+
+def default_context(device: int = 0) -> Context:
+    """Process-wide context per device.  Raises SrNativeError when no MI355X / HIP device exists."""
+    with _default_lock:
+        ctx = _default_ctx.get(device)
+        if ctx is None:
+            ctx = Context(device)
+            _default_ctx[device] = ctx
+        return ctx

@@ -1,0 +1,1572 @@
+// sr_engine.hip -- gfx950 (CDNA4) kernels and the device side of the C ABI in include/sr_hip.h.
+//
+// Numerics contract: every fp32 expression is evaluated in the order written in
+// oracle/sr_oracle.c (build with -ffp-contract=off), so the blend agrees with the CPU
+// restatement bit for bit.  fp64 is used only in the SSIM kernels.
+//
+// Data layout in HBM
+//   * external images / tiles / canvas: row-major HWC, u8 (or fp32 tiles), byte strides --
+//     exactly the reference's ndarrays.
+//   * internal pyramid levels i >= 1 of every tile live in one arena: planar fp32, plane
+//     c of level i at  off[i] + c * H_i * P_i,  row pitch P_i = round_up(W_i, 16) floats.
+//     G_i = Gaussian level, R_i = collapsed weighted-Laplacian level, W_i = weight level
+//     (one per distinct tile shape).
+//   * the fp32 canvas accumulators of the reference are never materialised: the final kernel
+//     is canvas-centric (gather) and sums the covering tiles in list order in registers.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "sr_internal.h"
+
+#define HIPCHK(expr)                                                                               \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return sr_set_error(SR_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                                __LINE__);                                                         \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+struct ProfPair {
+    int name_id;
+    hipEvent_t a, b;
+};
+
+struct sr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::recursive_mutex mu;
+    bool prof = false;
+    std::vector<std::string> prof_names;
+    std::vector<ProfPair> prof_pairs;
+    std::vector<hipEvent_t> ev_pool;
+    // small reusable device scratch (resize tables, reduction partials, result words)
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    // host copies of small tables handed to hipMemcpyAsync; released at the next stream sync
+    std::vector<std::vector<char>> pending_host;
+};
+
+// Enqueue a small host->device table upload whose source stays alive until the next sync.
+static hipError_t upload_small(sr_ctx *c, void *d_dst, const void *h_src, size_t bytes)
+{
+    c->pending_host.emplace_back((const char *)h_src, (const char *)h_src + bytes);
+    return hipMemcpyAsync(d_dst, c->pending_host.back().data(), bytes, hipMemcpyHostToDevice, c->stream);
+}
+
+static hipError_t stream_sync(sr_ctx *c)
+{
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) c->pending_host.clear();
+    return e;
+}
+
+static int ctx_scratch(sr_ctx *c, size_t bytes, void **out)
+{
+    if (bytes > c->scratch_bytes) {
+        if (c->scratch) {
+            HIPCHK(stream_sync(c));
+            HIPCHK(hipFree(c->scratch));
+            c->scratch = nullptr;
+            c->scratch_bytes = 0;
+        }
+        size_t nb = std::max(bytes, (size_t)1 << 20);
+        HIPCHK(hipMalloc(&c->scratch, nb));
+        c->scratch_bytes = nb;
+    }
+    *out = c->scratch;
+    return SR_OK;
+}
+
+struct Guard {
+    sr_ctx *c;
+    int prev = -1;
+    bool ok = true;
+    explicit Guard(sr_ctx *ctx) : c(ctx)
+    {
+        c->mu.lock();
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != c->device && hipSetDevice(c->device) != hipSuccess) ok = false;
+    }
+    ~Guard()
+    {
+        if (prev >= 0 && prev != c->device) (void)hipSetDevice(prev);
+        c->mu.unlock();
+    }
+};
+
+#define CTX_ENTER(ctx)                                                               \
+    if (!(ctx)) return sr_set_error(SR_ERR_INVALID_ARG, "%s: null context", __func__); \
+    Guard guard_(ctx);                                                               \
+    if (!guard_.ok) return sr_set_error(SR_ERR_HIP, "%s: hipSetDevice(%d) failed", __func__, (ctx)->device)
+
+static hipEvent_t prof_event(sr_ctx *c)
+{
+    if (!c->ev_pool.empty()) {
+        hipEvent_t e = c->ev_pool.back();
+        c->ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct ProfScope {
+    sr_ctx *c;
+    ProfPair p{};
+    bool on;
+    ProfScope(sr_ctx *ctx, const char *name) : c(ctx), on(ctx->prof)
+    {
+        if (!on) return;
+        int id = -1;
+        for (size_t i = 0; i < c->prof_names.size(); ++i)
+            if (c->prof_names[i] == name) id = (int)i;
+        if (id < 0) {
+            c->prof_names.push_back(name);
+            id = (int)c->prof_names.size() - 1;
+        }
+        p.name_id = id;
+        p.a = prof_event(c);
+        p.b = prof_event(c);
+        (void)hipEventRecord(p.a, c->stream);
+    }
+    ~ProfScope()
+    {
+        if (!on) return;
+        (void)hipEventRecord(p.b, c->stream);
+        c->prof_pairs.push_back(p);
+    }
+};
+
+static int check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return sr_set_error(SR_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return SR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+enum { PAD_MIRROR = 0, PAD_REPLICATE = 1, PAD_REFLECT = 2, PAD_CONSTANT = 3 };
+
+__device__ __forceinline__ int border_index(int p, int n, int mode)
+{
+    if (p >= 0 && p < n) return p;
+    if (mode == PAD_REPLICATE) return p < 0 ? 0 : n - 1;
+    if (n == 1) return 0;
+    const int delta = (mode == PAD_MIRROR) ? 1 : 0;
+    while (p < 0 || p >= n) {
+        if (p < 0) p = -p - 1 + delta;
+        else p = n - 1 - (p - n) - delta;
+    }
+    return p;
+}
+
+__device__ __forceinline__ int reflect101(int p, int n) { return border_index(p, n, PAD_MIRROR); }
+
+// One axis of cv2.pyrUp, unnormalised (x8): value of destination column x from source row `row`.
+__device__ __forceinline__ float up_h(const float *__restrict__ row, int ws, int x)
+{
+    const int sx = x >> 1;
+    if (ws == 1) return (x & 1) ? row[0] * 8.0f : row[0] * 6.0f + row[0] * 2.0f;
+    if (!(x & 1)) {
+        if (sx == 0) return row[0] * 6.0f + row[1] * 2.0f;
+        if (sx == ws - 1) return row[sx - 1] + row[sx] * 7.0f;
+        return (row[sx - 1] + row[sx] * 6.0f) + row[sx + 1];
+    }
+    if (sx == ws - 1) return row[sx] * 8.0f;
+    return (row[sx] + row[sx + 1]) * 4.0f;
+}
+
+// cv2.pyrUp sample at destination (y, x) from one planar fp32 source plane (hs x ws, pitch).
+__device__ __forceinline__ float up_sample(const float *__restrict__ src, int hs, int ws, int pitch, int y,
+                                           int x)
+{
+    const int sy = y >> 1;
+    const int yp = min(sy + 1, hs - 1);
+    const float r1 = up_h(src + (size_t)sy * pitch, ws, x);
+    const float r2 = up_h(src + (size_t)yp * pitch, ws, x);
+    if (!(y & 1)) {
+        const int ym = (sy - 1 < 0) ? (hs > 1 ? 1 : 0) : sy - 1;
+        const float r0 = up_h(src + (size_t)ym * pitch, ws, x);
+        return ((r0 + r1 * 6.0f) + r2) * (1.0f / 64.0f);
+    }
+    return ((r1 + r2) * 4.0f) * (1.0f / 64.0f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// blend plan tables
+// ---------------------------------------------------------------------------------------------
+struct TileDev {
+    int h, w, x, y;
+    int nl, fw, lut_off, cls;
+    int H[SR_MAX_LEVELS], W[SR_MAX_LEVELS], P[SR_MAX_LEVELS];
+    long long g_off[SR_MAX_LEVELS], r_off[SR_MAX_LEVELS], w_off[SR_MAX_LEVELS];
+    int g0[SR_MAX_LEVELS], g1[SR_MAX_LEVELS];  // G row windows
+    int r0[SR_MAX_LEVELS], r1[SR_MAX_LEVELS];  // R row windows
+};
+
+struct TileSrc {
+    const void *p;
+    long long stride;
+};
+
+enum { SRC_U8 = 0, SRC_F32 = 1, SRC_PLANAR = 2, SRC_LUT = 3 };
+
+// Source accessors for the pyrDown kernel -----------------------------------------------------
+template <int SRC>
+struct SrcRow;  // row(r) then at(x, c)
+
+// level i -> i+1 of every tile (or weight class) in one launch.  One thread = one output pixel,
+// all planes.  Rows limited to the G window of the destination level.
+template <int SRC>
+__global__ __launch_bounds__(256) void k_down(const TileDev *__restrict__ tiles, const TileSrc *__restrict__ srcs,
+                                              int lvl, int cn, float *__restrict__ arena,
+                                              const float *__restrict__ luts)
+{
+    const TileDev &T = tiles[blockIdx.z];
+    if (lvl + 1 >= T.nl) return;
+    const int wo = T.W[lvl + 1];
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = T.g0[lvl + 1] + blockIdx.y * 4 + threadIdx.y;
+    if (x >= wo || y >= T.g1[lvl + 1]) return;
+    const int hs = T.H[lvl], ws = T.W[lvl];
+    int xi[5], yi[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        xi[k] = reflect101(2 * x + k - 2, ws);
+        yi[k] = reflect101(2 * y + k - 2, hs);
+    }
+    const int po = T.P[lvl + 1];
+    float *dst = arena + T.g_off[lvl + 1] + (size_t)y * po + x;
+    const size_t dplane = (size_t)T.H[lvl + 1] * po;
+    for (int c = 0; c < cn; ++c) {
+        float rowv[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            float s[5];
+            if (SRC == SRC_U8) {
+                const unsigned char *r = (const unsigned char *)srcs[blockIdx.z].p + (size_t)yi[k] * srcs[blockIdx.z].stride;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) s[j] = (float)r[xi[j] * cn + c];
+            } else if (SRC == SRC_F32) {
+                const float *r = (const float *)((const char *)srcs[blockIdx.z].p + (size_t)yi[k] * srcs[blockIdx.z].stride);
+#pragma unroll
+                for (int j = 0; j < 5; ++j) s[j] = r[xi[j] * cn + c];
+            } else if (SRC == SRC_PLANAR) {
+                const float *r = arena + T.g_off[lvl] + (size_t)c * hs * T.P[lvl] + (size_t)yi[k] * T.P[lvl];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) s[j] = r[xi[j]];
+            } else {  // SRC_LUT: analytic weight map, level 0 of a weight class
+                const int ry = yi[k];
+                const int dy = min(ry, hs - 1 - ry);
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const int dx = min(xi[j], ws - 1 - xi[j]);
+                    s[j] = luts[T.lut_off + min(min(dy, dx), T.fw)];
+                }
+            }
+            rowv[k] = ((s[2] * 6.0f + (s[1] + s[3]) * 4.0f) + s[0]) + s[4];
+        }
+        const float v = ((rowv[2] * 6.0f + (rowv[1] + rowv[3]) * 4.0f) + rowv[0]) + rowv[4];
+        dst[c * dplane] = v * (1.0f / 256.0f);
+    }
+}
+
+// R_i for one level of every tile:  top level: G*W;  else up(R_{i+1}) + (G_i - up(G_{i+1})) * W_i
+__global__ __launch_bounds__(256) void k_up_level(const TileDev *__restrict__ tiles, int lvl, int cn,
+                                                  float *__restrict__ arena)
+{
+    const TileDev &T = tiles[blockIdx.z];
+    if (lvl >= T.nl) return;
+    const int w = T.W[lvl], h = T.H[lvl], p = T.P[lvl];
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = T.r0[lvl] + blockIdx.y * 4 + threadIdx.y;
+    if (x >= w || y >= T.r1[lvl]) return;
+    const float wv = arena[T.w_off[lvl] + (size_t)y * p + x];
+    const size_t plane = (size_t)h * p;
+    const float *g = arena + T.g_off[lvl] + (size_t)y * p + x;
+    float *r = arena + T.r_off[lvl] + (size_t)y * p + x;
+    if (lvl == T.nl - 1) {
+        for (int c = 0; c < cn; ++c) r[c * plane] = g[c * plane] * wv;
+        return;
+    }
+    const int hs = T.H[lvl + 1], ws = T.W[lvl + 1], ps = T.P[lvl + 1];
+    const size_t splane = (size_t)hs * ps;
+    const float *gs = arena + T.g_off[lvl + 1];
+    const float *rs = arena + T.r_off[lvl + 1];
+    for (int c = 0; c < cn; ++c) {
+        const float ug = up_sample(gs + c * splane, hs, ws, ps, y, x);
+        const float ur = up_sample(rs + c * splane, hs, ws, ps, y, x);
+        const float lap = g[c * plane] - ug;
+        const float wl = lap * wv;
+        r[c * plane] = ur + wl;
+    }
+}
+
+// Final level, canvas-centric: for each canvas pixel sum the covering tiles in list order
+// (acc += R_0, wacc += W_0), normalise, clip, truncate.  LAP == false: weighted_average_fusion.
+template <int DT, bool LAP>
+__global__ __launch_bounds__(256) void k_final(const TileDev *__restrict__ tiles, const TileSrc *__restrict__ srcs,
+                                               int n, int cn, const float *__restrict__ arena,
+                                               const float *__restrict__ luts, unsigned char *__restrict__ canvas,
+                                               long long cstride, float *__restrict__ canvas_f32, int cw,
+                                               int row_begin, int row_end)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = row_begin + blockIdx.y * 4 + threadIdx.y;
+    if (x >= cw || y >= row_end) return;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float wacc = 0.f;
+    for (int t = 0; t < n; ++t) {
+        const TileDev &T = tiles[t];
+        const int lx = x - T.x, ly = y - T.y;
+        if (lx < 0 || ly < 0 || lx >= T.w || ly >= T.h) continue;
+        const int d = min(min(ly, T.h - 1 - ly), min(lx, T.w - 1 - lx));
+        const float w0 = luts[T.lut_off + min(d, T.fw)];
+        const char *srow = (const char *)srcs[t].p + (size_t)ly * srcs[t].stride;
+        for (int c = 0; c < cn; ++c) {
+            float g0;
+            if (DT == SRC_U8) g0 = (float)((const unsigned char *)srow)[lx * cn + c];
+            else g0 = ((const float *)srow)[lx * cn + c];
+            float r;
+            if (LAP && T.nl > 1) {
+                const int hs = T.H[1], ws = T.W[1], ps = T.P[1];
+                const size_t splane = (size_t)hs * ps;
+                const float ug = up_sample(arena + T.g_off[1] + c * splane, hs, ws, ps, ly, lx);
+                const float ur = up_sample(arena + T.r_off[1] + c * splane, hs, ws, ps, ly, lx);
+                const float lap = g0 - ug;
+                const float wl = lap * w0;
+                r = ur + wl;
+            } else {
+                r = g0 * w0;
+            }
+            acc[c] += r;
+        }
+        wacc += w0;
+    }
+    const float wv = wacc > 1e-6f ? wacc : 1e-6f;
+    unsigned char *o = canvas + (size_t)y * cstride + (size_t)x * cn;
+    for (int c = 0; c < cn; ++c) {
+        const float v = acc[c] / wv;
+        if (canvas_f32) canvas_f32[((size_t)y * cw + x) * cn + c] = v;
+        const float cl = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
+        o[c] = (unsigned char)cl;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dense HWC pyramid primitives (API utilities for build_gaussian_pyramid & friends)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pyr_down_hwc(const float *__restrict__ src, int h, int w, int cn,
+                                                      float *__restrict__ dst, int ho, int wo)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= wo || y >= ho) return;
+    int xi[5], yi[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        xi[k] = reflect101(2 * x + k - 2, w);
+        yi[k] = reflect101(2 * y + k - 2, h);
+    }
+    for (int c = 0; c < cn; ++c) {
+        float rowv[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const float *r = src + (size_t)yi[k] * w * cn + c;
+            rowv[k] = ((r[xi[2] * cn] * 6.0f + (r[xi[1] * cn] + r[xi[3] * cn]) * 4.0f) + r[xi[0] * cn]) + r[xi[4] * cn];
+        }
+        const float v = ((rowv[2] * 6.0f + (rowv[1] + rowv[3]) * 4.0f) + rowv[0]) + rowv[4];
+        dst[((size_t)y * wo + x) * cn + c] = v * (1.0f / 256.0f);
+    }
+}
+
+__device__ __forceinline__ float up_h_hwc(const float *__restrict__ row, int ws, int cn, int x)
+{
+    const int sx = x >> 1;
+    if (ws == 1) return (x & 1) ? row[0] * 8.0f : row[0] * 6.0f + row[0] * 2.0f;
+    if (!(x & 1)) {
+        if (sx == 0) return row[0] * 6.0f + row[cn] * 2.0f;
+        if (sx == ws - 1) return row[(sx - 1) * cn] + row[sx * cn] * 7.0f;
+        return (row[(sx - 1) * cn] + row[sx * cn] * 6.0f) + row[(sx + 1) * cn];
+    }
+    if (sx == ws - 1) return row[sx * cn] * 8.0f;
+    return (row[sx * cn] + row[(sx + 1) * cn]) * 4.0f;
+}
+
+// MODE 0: dst = up(src); 1: dst = a - up(src); 2: dst = up(src) + a
+template <int MODE>
+__global__ __launch_bounds__(256) void k_pyr_up_hwc(const float *__restrict__ src, int hs, int ws, int cn,
+                                                    const float *__restrict__ a, float *__restrict__ dst, int hd,
+                                                    int wd)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= wd || y >= hd) return;
+    const int sy = y >> 1;
+    const int yp = min(sy + 1, hs - 1);
+    const int ym = (sy - 1 < 0) ? (hs > 1 ? 1 : 0) : sy - 1;
+    for (int c = 0; c < cn; ++c) {
+        const float r1 = up_h_hwc(src + (size_t)sy * ws * cn + c, ws, cn, x);
+        const float r2 = up_h_hwc(src + (size_t)yp * ws * cn + c, ws, cn, x);
+        float u;
+        if (!(y & 1)) {
+            const float r0 = up_h_hwc(src + (size_t)ym * ws * cn + c, ws, cn, x);
+            u = ((r0 + r1 * 6.0f) + r2) * (1.0f / 64.0f);
+        } else {
+            u = ((r1 + r2) * 4.0f) * (1.0f / 64.0f);
+        }
+        const size_t o = ((size_t)y * wd + x) * cn + c;
+        if (MODE == 0) dst[o] = u;
+        else if (MODE == 1) dst[o] = a[o] - u;
+        else dst[o] = u + a[o];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// tile extract
+// ---------------------------------------------------------------------------------------------
+struct ExtractDesc {
+    int x, y, w, h;
+    unsigned char *dst;
+    long long dstride;
+    int out_w, out_h;
+};
+
+__global__ __launch_bounds__(256) void k_tile_extract(const unsigned char *__restrict__ img, long long istride,
+                                                      int cn, const ExtractDesc *__restrict__ descs, int pad_mode)
+{
+    const ExtractDesc D = descs[blockIdx.z];
+    const int c = blockIdx.x * 64 + threadIdx.x, r = blockIdx.y * 4 + threadIdx.y;
+    if (c >= D.out_w || r >= D.out_h) return;
+    unsigned char *d = D.dst + (size_t)r * D.dstride + (size_t)c * cn;
+    if (pad_mode == PAD_CONSTANT && (r >= D.h || c >= D.w)) {
+        for (int k = 0; k < cn; ++k) d[k] = 0;
+        return;
+    }
+    const int sr = border_index(r, D.h, pad_mode), sc = border_index(c, D.w, pad_mode);
+    const unsigned char *s = img + (size_t)(D.y + sr) * istride + (size_t)(D.x + sc) * cn;
+    for (int k = 0; k < cn; ++k) d[k] = s[k];
+}
+
+// ---------------------------------------------------------------------------------------------
+// metrics
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// contiguous fast path: both buffers dense and 16-byte aligned
+__global__ __launch_bounds__(256) void k_sse_flat(const uint4 *__restrict__ a, const uint4 *__restrict__ b,
+                                                  size_t nvec, const unsigned char *__restrict__ ta,
+                                                  const unsigned char *__restrict__ tb, int ntail,
+                                                  unsigned long long *__restrict__ out)
+{
+    unsigned long long s = 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        const uint4 va = a[i], vb = b[i];
+        const unsigned int wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
+        unsigned int p = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int d = (int)((wa[k] >> (8 * j)) & 0xFF) - (int)((wb[k] >> (8 * j)) & 0xFF);
+                p += (unsigned int)(d * d);
+            }
+        s += p;
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) {
+        const int d = (int)ta[threadIdx.x] - (int)tb[threadIdx.x];
+        s += (unsigned int)(d * d);
+    }
+    s = wave_sum_u64(s);
+    __shared__ unsigned long long ws[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) ws[wid] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, ws[0] + ws[1] + ws[2] + ws[3]);
+}
+
+// strided path (cropped / non-dense images): one block row-chunk, byte loads
+__global__ __launch_bounds__(256) void k_sse_rows(const unsigned char *__restrict__ a, long long sa,
+                                                  const unsigned char *__restrict__ b, long long sb, int h,
+                                                  long long rowlen, unsigned long long *__restrict__ out)
+{
+    unsigned long long s = 0;
+    for (int y = blockIdx.y; y < h; y += gridDim.y) {
+        const unsigned char *pa = a + (size_t)y * sa, *pb = b + (size_t)y * sb;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < rowlen;
+             i += (long long)gridDim.x * blockDim.x) {
+            const int d = (int)pa[i] - (int)pb[i];
+            s += (unsigned int)(d * d);
+        }
+    }
+    s = wave_sum_u64(s);
+    __shared__ unsigned long long ws[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) ws[wid] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, ws[0] + ws[1] + ws[2] + ws[3]);
+}
+
+__device__ __forceinline__ int gray_of(const unsigned char *__restrict__ p, int cn, int shift)
+{
+    if (cn == 1) return p[0];
+    const int r = p[0], g = p[1], b = p[2];
+    return shift == 15 ? (r * 9798 + g * 19235 + b * 3735 + (1 << 14)) >> 15
+                       : (r * 4899 + g * 9617 + b * 1868 + (1 << 13)) >> 14;
+}
+
+__global__ __launch_bounds__(256) void k_rgb2gray(const unsigned char *__restrict__ rgb, long long stride, int h,
+                                                  int w, int shift, unsigned char *__restrict__ gray,
+                                                  long long gstride)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    gray[(size_t)y * gstride + x] = (unsigned char)gray_of(rgb + (size_t)y * stride + (size_t)x * 3, 3, shift);
+}
+
+// SSIM.  One block = SS_TX x SS_TY map samples.  Gray halo tile in LDS, separable fp64 filter
+// (rows pass into LDS, then columns), SSIM formula, block sum -> partials[block].
+#define SS_TX 32
+#define SS_TY 16
+#define SS_R 5  // max radius (11 taps)
+
+struct SsimParams {
+    int h, w, cn, shift;
+    int klen, rad, bmode;      // filter taps, radius, border rule for taps outside the image
+    int vy0, vy1, vx0, vx1;    // map region summed (valid region ∩ row range)
+    double cov_norm, c1, c2;
+    double k[11];
+};
+
+__global__ __launch_bounds__(256) void k_ssim(const unsigned char *__restrict__ a, long long sa,
+                                              const unsigned char *__restrict__ b, long long sb, SsimParams P,
+                                              double *__restrict__ partials)
+{
+    __shared__ unsigned char gx[SS_TY + 2 * SS_R][SS_TX + 2 * SS_R];
+    __shared__ unsigned char gy[SS_TY + 2 * SS_R][SS_TX + 2 * SS_R];
+    __shared__ double hb[5][SS_TY + 2 * SS_R][SS_TX];
+    __shared__ double wsum[4];
+    const int tid = threadIdx.x;
+    const int bx0 = P.vx0 + blockIdx.x * SS_TX, by0 = P.vy0 + blockIdx.y * SS_TY;
+    const int R = P.rad;
+    const int TW = SS_TX + 2 * R, TH = SS_TY + 2 * R;
+    for (int i = tid; i < TW * TH; i += 256) {
+        const int ly = i / TW, lx = i - ly * TW;
+        const int sy = border_index(by0 + ly - R, P.h, P.bmode);
+        const int sx = border_index(bx0 + lx - R, P.w, P.bmode);
+        gx[ly][lx] = (unsigned char)gray_of(a + (size_t)sy * sa + (size_t)sx * P.cn, P.cn, P.shift);
+        gy[ly][lx] = (unsigned char)gray_of(b + (size_t)sy * sb + (size_t)sx * P.cn, P.cn, P.shift);
+    }
+    __syncthreads();
+    for (int i = tid; i < SS_TX * TH; i += 256) {
+        const int ly = i / SS_TX, lx = i - ly * SS_TX;
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+        for (int j = 0; j < P.klen; ++j) {
+            const int xv = gx[ly][lx + j], yv = gy[ly][lx + j];
+            const double kw = P.k[j];
+            s0 += (double)xv * kw;
+            s1 += (double)yv * kw;
+            s2 += (double)(xv * xv) * kw;
+            s3 += (double)(yv * yv) * kw;
+            s4 += (double)(xv * yv) * kw;
+        }
+        hb[0][ly][lx] = s0;
+        hb[1][ly][lx] = s1;
+        hb[2][ly][lx] = s2;
+        hb[3][ly][lx] = s3;
+        hb[4][ly][lx] = s4;
+    }
+    __syncthreads();
+    double local = 0.0;
+    for (int i = tid; i < SS_TX * SS_TY; i += 256) {
+        const int ly = i / SS_TX, lx = i - ly * SS_TX;
+        const int my = by0 + ly, mx = bx0 + lx;
+        if (my >= P.vy1 || mx >= P.vx1) continue;
+        double ux = 0, uy = 0, uxx = 0, uyy = 0, uxy = 0;
+        for (int j = 0; j < P.klen; ++j) {
+            const double kw = P.k[j];
+            ux += hb[0][ly + j][lx] * kw;
+            uy += hb[1][ly + j][lx] * kw;
+            uxx += hb[2][ly + j][lx] * kw;
+            uyy += hb[3][ly + j][lx] * kw;
+            uxy += hb[4][ly + j][lx] * kw;
+        }
+        const double vx = P.cov_norm * (uxx - ux * ux);
+        const double vy = P.cov_norm * (uyy - uy * uy);
+        const double vxy = P.cov_norm * (uxy - ux * uy);
+        const double a1 = 2 * ux * uy + P.c1, a2 = 2 * vxy + P.c2;
+        const double b1 = ux * ux + uy * uy + P.c1, b2 = vx + vy + P.c2;
+        local += (a1 * a2) / (b1 * b2);
+    }
+    local = wave_sum_f64(local);
+    if ((tid & 63) == 0) wsum[tid >> 6] = local;
+    __syncthreads();
+    if (tid == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+}
+
+// deterministic final sum of the per-block partials (fixed order)
+__global__ __launch_bounds__(256) void k_sum_partials(const double *__restrict__ partials, int n,
+                                                      double *__restrict__ out)
+{
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+// ---------------------------------------------------------------------------------------------
+// cv2.resize INTER_CUBIC, u8
+// ---------------------------------------------------------------------------------------------
+struct CubicTab {
+    int ofs;
+    short c[4];
+};
+
+__global__ __launch_bounds__(256) void k_resize_cubic(const unsigned char *__restrict__ src, long long sstride,
+                                                      int h, int w, int cn, const CubicTab *__restrict__ xt,
+                                                      const CubicTab *__restrict__ yt, int x0, int y0, int ww,
+                                                      int wh, unsigned char *__restrict__ dst, long long dstride)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= ww || y >= wh) return;
+    const CubicTab X = xt[x0 + x], Y = yt[y0 + y];
+    int sx[4], sy[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sx[k] = min(max(X.ofs + k - 1, 0), w - 1) * cn;
+        sy[k] = min(max(Y.ofs + k - 1, 0), h - 1);
+    }
+    for (int c = 0; c < cn; ++c) {
+        long long acc = 0;
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky) {
+            const unsigned char *r = src + (size_t)sy[ky] * sstride + c;
+            const int hs = (int)r[sx[0]] * X.c[0] + (int)r[sx[1]] * X.c[1] + (int)r[sx[2]] * X.c[2] +
+                           (int)r[sx[3]] * X.c[3];
+            acc += (long long)hs * Y.c[ky];
+        }
+        const long long v = (acc + (1 << 21)) >> 22;
+        dst[(size_t)y * dstride + (size_t)x * cn + c] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+}
+
+static void cubic_table(int n_src, int n_dst, std::vector<CubicTab> &tab)
+{
+    tab.resize(n_dst);
+    const double scale = 1.0 / ((double)n_dst / (double)n_src);
+    for (int d = 0; d < n_dst; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        const int s = (int)floorf(f);
+        f -= (float)s;
+        const float A = -0.75f;
+        float c[4];
+        c[0] = ((A * (f + 1.0f) - 5.0f * A) * (f + 1.0f) + 8.0f * A) * (f + 1.0f) - 4.0f * A;
+        c[1] = ((A + 2.0f) * f - (A + 3.0f)) * f * f + 1.0f;
+        const float f2 = 1.0f - f;
+        c[2] = ((A + 2.0f) * f2 - (A + 3.0f)) * f2 * f2 + 1.0f;
+        c[3] = 1.0f - c[0] - c[1] - c[2];
+        tab[d].ofs = s;
+        for (int k = 0; k < 4; ++k) {
+            const float v = rintf(c[k] * 2048.0f);
+            tab[d].c[k] = (short)(v < -32768.f ? -32768.f : (v > 32767.f ? 32767.f : v));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// blend plan (host object)
+// ---------------------------------------------------------------------------------------------
+struct sr_blend_plan {
+    sr_ctx *ctx = nullptr;
+    int n = 0, cn = 3, canvas_h = 0, canvas_w = 0, levels = 6, wtype = 1, row_begin = 0, row_end = 0;
+    int max_nl = 1;
+    std::vector<TileDev> tiles;     // per tile
+    std::vector<TileDev> classes;   // per weight class (pseudo tiles, cn = 1, g_off = weight levels)
+    std::vector<SrWin> tile_rows;   // rows of the input tiles that are read
+    std::vector<float> luts;
+    size_t arena_floats = 0;
+    float *d_arena = nullptr;
+    TileDev *d_tiles = nullptr, *d_classes = nullptr;
+    TileSrc *d_srcs = nullptr;
+    float *d_luts = nullptr;
+    // launch extents per level
+    int max_w[SR_MAX_LEVELS] = {0}, max_grows[SR_MAX_LEVELS] = {0}, max_rrows[SR_MAX_LEVELS] = {0};
+    int cmax_w[SR_MAX_LEVELS] = {0}, cmax_rows[SR_MAX_LEVELS] = {0};
+};
+
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+extern "C" {
+
+int sr_device_count(int *count)
+{
+    if (!count) return sr_set_error(SR_ERR_INVALID_ARG, "sr_device_count: null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return sr_set_error(SR_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return SR_OK;
+}
+
+static int ctx_create_impl(int device_id, void *stream, bool adopt, sr_ctx **out)
+{
+    if (!out) return sr_set_error(SR_ERR_INVALID_ARG, "sr_ctx_create: null out");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return sr_set_error(SR_ERR_HIP, "sr_ctx_create: no HIP device available (%s)",
+                            e == hipSuccess ? "count is 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n)
+        return sr_set_error(SR_ERR_INVALID_ARG, "sr_ctx_create: device %d out of range (0..%d)", device_id, n - 1);
+    int prev = 0;
+    HIPCHK(hipGetDevice(&prev));
+    HIPCHK(hipSetDevice(device_id));
+    sr_ctx *c = new sr_ctx();
+    c->device = device_id;
+    if (adopt) {
+        c->stream = (hipStream_t)stream;
+        c->own_stream = false;
+    } else {
+        hipError_t e2 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e2 != hipSuccess) {
+            delete c;
+            (void)hipSetDevice(prev);
+            return sr_set_error(SR_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e2));
+        }
+        c->own_stream = true;
+    }
+    (void)hipSetDevice(prev);
+    *out = c;
+    return SR_OK;
+}
+
+int sr_ctx_create(int device_id, sr_ctx **out) { return ctx_create_impl(device_id, nullptr, false, out); }
+
+int sr_ctx_create_on_stream(int device_id, void *hip_stream, sr_ctx **out)
+{
+    return ctx_create_impl(device_id, hip_stream, true, out);
+}
+
+int sr_ctx_destroy(sr_ctx *ctx)
+{
+    if (!ctx) return SR_OK;
+    {
+        Guard g(ctx);
+        (void)hipStreamSynchronize(ctx->stream);
+        for (auto &p : ctx->prof_pairs) {
+            (void)hipEventDestroy(p.a);
+            (void)hipEventDestroy(p.b);
+        }
+        for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+        if (ctx->scratch) (void)hipFree(ctx->scratch);
+        if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    }
+    delete ctx;
+    return SR_OK;
+}
+
+int sr_ctx_sync(sr_ctx *ctx)
+{
+    CTX_ENTER(ctx);
+    HIPCHK(stream_sync(ctx));
+    return SR_OK;
+}
+
+int sr_dev_alloc(sr_ctx *ctx, size_t bytes, void **d_ptr)
+{
+    CTX_ENTER(ctx);
+    if (!d_ptr) return sr_set_error(SR_ERR_INVALID_ARG, "sr_dev_alloc: null out");
+    *d_ptr = nullptr;
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(d_ptr, bytes);
+    if (e == hipErrorOutOfMemory) return sr_set_error(SR_ERR_OOM, "sr_dev_alloc: out of device memory (%zu B)", bytes);
+    if (e != hipSuccess) return sr_set_error(SR_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e));
+    return SR_OK;
+}
+
+int sr_dev_free(sr_ctx *ctx, void *d_ptr)
+{
+    CTX_ENTER(ctx);
+    if (!d_ptr) return SR_OK;
+    HIPCHK(stream_sync(ctx));
+    HIPCHK(hipFree(d_ptr));
+    return SR_OK;
+}
+
+int sr_memcpy_h2d(sr_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
+{
+    CTX_ENTER(ctx);
+    if (bytes == 0) return SR_OK;
+    HIPCHK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(stream_sync(ctx));
+    return SR_OK;
+}
+
+int sr_memcpy_d2h(sr_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
+{
+    CTX_ENTER(ctx);
+    if (bytes == 0) return SR_OK;
+    HIPCHK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(stream_sync(ctx));
+    return SR_OK;
+}
+
+int sr_memcpy_d2d(sr_ctx *ctx, void *d_dst, const void *d_src, size_t bytes)
+{
+    CTX_ENTER(ctx);
+    if (bytes == 0) return SR_OK;
+    HIPCHK(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return SR_OK;
+}
+
+int sr_memset_d(sr_ctx *ctx, void *d_dst, int value, size_t bytes)
+{
+    CTX_ENTER(ctx);
+    if (bytes == 0) return SR_OK;
+    HIPCHK(hipMemsetAsync(d_dst, value, bytes, ctx->stream));
+    return SR_OK;
+}
+
+int sr_prof_enable(sr_ctx *ctx, int on)
+{
+    CTX_ENTER(ctx);
+    ctx->prof = on != 0;
+    return SR_OK;
+}
+
+int sr_prof_reset(sr_ctx *ctx)
+{
+    CTX_ENTER(ctx);
+    HIPCHK(stream_sync(ctx));
+    for (auto &p : ctx->prof_pairs) {
+        ctx->ev_pool.push_back(p.a);
+        ctx->ev_pool.push_back(p.b);
+    }
+    ctx->prof_pairs.clear();
+    return SR_OK;
+}
+
+int sr_prof_get(sr_ctx *ctx, sr_prof_record *h_records, int cap, int *n)
+{
+    CTX_ENTER(ctx);
+    if (!n) return sr_set_error(SR_ERR_INVALID_ARG, "sr_prof_get: null n");
+    HIPCHK(stream_sync(ctx));
+    std::vector<double> ms(ctx->prof_names.size(), 0.0);
+    std::vector<int64_t> cnt(ctx->prof_names.size(), 0);
+    for (auto &p : ctx->prof_pairs) {
+        float t = 0.f;
+        HIPCHK(hipEventElapsedTime(&t, p.a, p.b));
+        ms[p.name_id] += t;
+        cnt[p.name_id] += 1;
+    }
+    int k = 0;
+    for (size_t i = 0; i < ctx->prof_names.size(); ++i) {
+        if (cnt[i] == 0) continue;
+        if (h_records && k < cap) {
+            memset(&h_records[k], 0, sizeof(sr_prof_record));
+            strncpy(h_records[k].name, ctx->prof_names[i].c_str(), sizeof(h_records[k].name) - 1);
+            h_records[k].ms = ms[i];
+            h_records[k].launches = cnt[i];
+        }
+        ++k;
+    }
+    *n = k;
+    return SR_OK;
+}
+
+// ---- tile extract ------------------------------------------------------------------------------
+static int extract_impl(sr_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, int cn, int64_t img_stride,
+                        const std::vector<ExtractDesc> &descs, int pad_mode, const char *name)
+{
+    const int n = (int)descs.size();
+    if (n == 0) return SR_OK;
+    int mw = 0, mh = 0;
+    for (auto &d : descs) {
+        if (d.x < 0 || d.y < 0 || d.w <= 0 || d.h <= 0 || d.x + d.w > img_w || d.y + d.h > img_h)
+            return sr_set_error(SR_ERR_SHAPE, "%s: tile (%d,%d,%d,%d) outside the %dx%d image", name, d.x, d.y, d.w,
+                                d.h, img_w, img_h);
+        mw = std::max(mw, d.out_w);
+        mh = std::max(mh, d.out_h);
+    }
+    void *scr = nullptr;
+    int rc = ctx_scratch(ctx, sizeof(ExtractDesc) * n, &scr);
+    if (rc) return rc;
+    HIPCHK(upload_small(ctx, scr, descs.data(), sizeof(ExtractDesc) * n));
+    {
+        ProfScope ps(ctx, name);
+        dim3 grid((mw + 63) / 64, (mh + 3) / 4, n), block(64, 4);
+        hipLaunchKernelGGL(k_tile_extract, grid, block, 0, ctx->stream, d_img, (long long)img_stride, cn,
+                           (const ExtractDesc *)scr, pad_mode);
+    }
+    return check_launch(name);
+}
+
+int sr_tile_extract_pad(sr_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, int cn, int64_t img_stride,
+                        const int *h_xywh, int n, int block_size, int pad_mode, uint8_t *d_tiles)
+{
+    CTX_ENTER(ctx);
+    if (!d_img || !h_xywh || !d_tiles || n < 0 || cn < 1 || cn > 4 || block_size <= 0 || pad_mode < 0 || pad_mode > 3)
+        return sr_set_error(SR_ERR_INVALID_ARG, "sr_tile_extract_pad: bad arguments");
+    std::vector<ExtractDesc> descs(n);
+    for (int i = 0; i < n; ++i) {
+        ExtractDesc &d = descs[i];
+        d.x = h_xywh[4 * i];
+        d.y = h_xywh[4 * i + 1];
+        d.w = h_xywh[4 * i + 2];
+        d.h = h_xywh[4 * i + 3];
+        if (d.w > block_size || d.h > block_size)
+            return sr_set_error(SR_ERR_SHAPE, "sr_tile_extract_pad: tile %d larger than block_size", i);
+        d.dst = d_tiles + (size_t)i * block_size * block_size * cn;
+        d.dstride = (long long)block_size * cn;
+        d.out_w = d.out_h = block_size;
+    }
+    return extract_impl(ctx, d_img, img_h, img_w, cn, img_stride, descs, pad_mode, "tile_extract_pad");
+}
+
+int sr_tile_extract(sr_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, int cn, int64_t img_stride,
+                    const int *h_xywh, int n, void *const *h_d_tiles, const int64_t *h_tile_strides)
+{
+    CTX_ENTER(ctx);
+    if (!d_img || !h_xywh || !h_d_tiles || !h_tile_strides || n < 0 || cn < 1 || cn > 4)
+        return sr_set_error(SR_ERR_INVALID_ARG, "sr_tile_extract: bad arguments");
+    std::vector<ExtractDesc> descs(n);
+    for (int i = 0; i < n; ++i) {
+        ExtractDesc &d = descs[i];
+        d.x = h_xywh[4 * i];
+        d.y = h_xywh[4 * i + 1];
+        d.w = h_xywh[4 * i + 2];
+        d.h = h_xywh[4 * i + 3];
+        d.dst = (unsigned char *)h_d_tiles[i];
+        d.dstride = h_tile_strides[i];
+        d.out_w = d.w;
+        d.out_h = d.h;
+    }
+    return extract_impl(ctx, d_img, img_h, img_w, cn, img_stride, descs, PAD_REPLICATE, "tile_extract");
+}
+
+// ---- dense pyramid primitives --------------------------------------------------------------------
+int sr_pyr_down(sr_ctx *ctx, const float *d_src, int h, int w, int cn, float *d_dst)
+{
+    CTX_ENTER(ctx);
+    if (!d_src || !d_dst || h < 1 || w < 1 || cn < 1 || cn > 4)
+        return sr_set_error(SR_ERR_INVALID_ARG, "sr_pyr_down: bad arguments");
+    const int ho = (h + 1) / 2, wo = (w + 1) / 2;
+    {
+        ProfScope ps(ctx, "pyr_down_hwc");
+        dim3 grid((wo + 63) / 64, (ho + 3) / 4), block(64, 4);
+        hipLaunchKernelGGL(k_pyr_down_hwc, grid, block, 0, ctx->stream, d_src, h, w, cn, d_dst, ho, wo);
+    }
+    return check_launch("pyr_down_hwc");
+}
+
+static int pyr_up_impl(sr_ctx *ctx, int mode, const float *d_src, int hs, int ws, int cn, const float *d_a,
+                       float *d_dst, int hd, int wd)
+{
+    if (!d_src || !d_dst || hs < 1 || ws < 1 || cn < 1 || cn > 4 || (mode && !d_a))
+        return sr_set_error(SR_ERR_INVALID_ARG, "sr_pyr_up: bad arguments");
+    if ((wd != 2 * ws && wd != 2 * ws - 1) || (hd != 2 * hs && hd != 2 * hs - 1) || wd < 1 || hd < 1)
+        return sr_set_error(SR_ERR_SHAPE, "sr_pyr_up: dst %dx%d is not 2x(-1) of src %dx%d", wd, hd, ws, hs);
+    {
+        ProfScope ps(ctx, "pyr_up_hwc");
+        dim3 grid((wd + 63) / 64, (hd + 3) / 4), block(64, 4);
+        if (mode == 0) hipLaunchKernelGGL(k_pyr_up_hwc<0>, grid, block, 0, ctx->stream, d_src, hs, ws, cn, d_a, d_dst, hd, wd);
+        else if (mode == 1) hipLaunchKernelGGL(k_pyr_up_hwc<1>, grid, block, 0, ctx->stream, d_src, hs, ws, cn, d_a, d_dst, hd, wd);
+        else hipLaunchKernelGGL(k_pyr_up_hwc<2>, grid, block, 0, ctx->stream, d_src, hs, ws, cn, d_a, d_dst, hd, wd);
+    }
+    return check_launch("pyr_up_hwc");
+}
+
+int sr_pyr_up(sr_ctx *ctx, const float *d_src, int hs, int ws, int cn, float *d_dst, int hd, int wd)
+{
+    CTX_ENTER(ctx);
+    return pyr_up_impl(ctx, 0, d_src, hs, ws, cn, nullptr, d_dst, hd, wd);
+}
+
+int sr_pyr_up_sub(sr_ctx *ctx, const float *d_a, int h, int w, int cn, const float *d_b, float *d_out)
+{
+    CTX_ENTER(ctx);
+    return pyr_up_impl(ctx, 1, d_b, (h + 1) / 2, (w + 1) / 2, cn, d_a, d_out, h, w);
+}
+
+int sr_pyr_up_add(sr_ctx *ctx, const float *d_a, int h, int w, int cn, const float *d_b, float *d_out)
+{
+    CTX_ENTER(ctx);
+    return pyr_up_impl(ctx, 2, d_b, (h + 1) / 2, (w + 1) / 2, cn, d_a, d_out, h, w);
+}
+
+// ---- blend plan ------------------------------------------------------------------------------------
+int sr_blend_plan_destroy(sr_blend_plan *plan)
+{
+    if (!plan) return SR_OK;
+    sr_ctx *ctx = plan->ctx;
+    {
+        Guard g(ctx);
+        (void)hipStreamSynchronize(ctx->stream);
+        if (plan->d_arena) (void)hipFree(plan->d_arena);
+        if (plan->d_tiles) (void)hipFree(plan->d_tiles);
+        if (plan->d_classes) (void)hipFree(plan->d_classes);
+        if (plan->d_srcs) (void)hipFree(plan->d_srcs);
+        if (plan->d_luts) (void)hipFree(plan->d_luts);
+    }
+    delete plan;
+    return SR_OK;
+}
+
+int sr_blend_plan_create(sr_ctx *ctx, const sr_tile_rect *h_tiles, int n, int cn, int canvas_h, int canvas_w,
+                         int levels, int weight_type, int row_begin, int row_end, sr_blend_plan **out)
+{
+    CTX_ENTER(ctx);
+    if (!out) return sr_set_error(SR_ERR_INVALID_ARG, "sr_blend_plan_create: null out");
+    *out = nullptr;
+    if (!h_tiles || n < 1 || n > 65535) return sr_set_error(SR_ERR_INVALID_ARG, "sr_blend_plan_create: need 1..65535 tiles");
+    if (cn < 1 || cn > 4) return sr_set_error(SR_ERR_INVALID_ARG, "sr_blend_plan_create: channels must be 1..4");
+    if (canvas_h < 1 || canvas_w < 1) return sr_set_error(SR_ERR_SHAPE, "sr_blend_plan_create: empty canvas");
+    if (levels < 1) return sr_set_error(SR_ERR_INVALID_ARG, "sr_blend_plan_create: levels must be >= 1");
+    if (weight_type < 0 || weight_type > 2) return sr_set_error(SR_ERR_INVALID_ARG, "sr_blend_plan_create: bad weight type");
+    row_begin = std::max(row_begin, 0);
+    row_end = std::min(row_end, canvas_h);
+    if (row_begin > row_end) row_begin = row_end;
+
+    sr_blend_plan *P = new sr_blend_plan();
+    P->ctx = ctx;
+    P->n = n;
+    P->cn = cn;
+    P->canvas_h = canvas_h;
+    P->canvas_w = canvas_w;
+    P->levels = std::min(levels, SR_MAX_LEVELS);
+    P->wtype = weight_type;
+    P->row_begin = row_begin;
+    P->row_end = row_end;
+    P->tiles.resize(n);
+    P->tile_rows.resize(n);
+
+    std::map<std::pair<int, int>, int> cls_of;
+    std::vector<SrTileLevels> lv(n);
+    size_t off = 0;
+    for (int t = 0; t < n; ++t) {
+        const sr_tile_rect &r = h_tiles[t];
+        if (r.w < 1 || r.h < 1 || r.x < 0 || r.y < 0) {
+            delete P;
+            return sr_set_error(SR_ERR_INVALID_ARG, "sr_blend_plan_create: tile %d has bad rectangle (%d,%d,%d,%d)", t, r.x,
+                                r.y, r.w, r.h);
+        }
+        if (std::min(r.w, r.h) < 8) {
+            delete P;
+            return sr_set_error(SR_ERR_INVALID_ARG,
+                                "sr_blend_plan_create: tile %d is %dx%d; min side < 8 gives the reference a zero "
+                                "feather width (NaN weights)", t, r.w, r.h);
+        }
+        sr_plan_windows(r.h, r.w, r.y, P->levels, row_begin, row_end, canvas_h, &lv[t]);
+        TileDev &T = P->tiles[t];
+        memset(&T, 0, sizeof(T));
+        T.h = r.h;
+        T.w = r.w;
+        T.x = r.x;
+        T.y = r.y;
+        T.nl = lv[t].nl;
+        T.fw = std::min(r.w, r.h) / 8;
+        P->max_nl = std::max(P->max_nl, T.nl);
+        auto key = std::make_pair(r.h, r.w);
+        auto it = cls_of.find(key);
+        if (it == cls_of.end()) {
+            const int id = (int)P->classes.size();
+            cls_of[key] = id;
+            TileDev C;
+            memset(&C, 0, sizeof(C));
+            C.h = r.h;
+            C.w = r.w;
+            C.nl = T.nl;
+            C.fw = T.fw;
+            C.lut_off = (int)P->luts.size();
+            P->luts.resize(P->luts.size() + T.fw + 1);
+            int rc = sr_weight_lut(T.fw, weight_type, P->luts.data() + C.lut_off);
+            if (rc) {
+                delete P;
+                return rc;
+            }
+            for (int i = 0; i < T.nl; ++i) {
+                C.H[i] = lv[t].H[i];
+                C.W[i] = lv[t].W[i];
+                C.P[i] = round_up(C.W[i], 16);
+                C.g0[i] = C.g1[i] = 0;
+                if (i >= 1) {
+                    C.g_off[i] = (long long)off;
+                    off += (size_t)C.H[i] * C.P[i];
+                }
+            }
+            P->classes.push_back(C);
+            T.cls = id;
+        } else {
+            T.cls = it->second;
+        }
+        TileDev &C = P->classes[T.cls];
+        T.lut_off = C.lut_off;
+        for (int i = 0; i < T.nl; ++i) {
+            T.H[i] = lv[t].H[i];
+            T.W[i] = lv[t].W[i];
+            T.P[i] = round_up(T.W[i], 16);
+            T.g0[i] = lv[t].gw[i].a;
+            T.g1[i] = lv[t].gw[i].b;
+            T.r0[i] = lv[t].rw[i].a;
+            T.r1[i] = lv[t].rw[i].b;
+            T.w_off[i] = C.g_off[i];
+            if (i >= 1) {
+                // weight level i must cover every member tile's G window (hull)
+                if (T.g0[i] < T.g1[i]) {
+                    if (C.g0[i] >= C.g1[i]) {
+                        C.g0[i] = T.g0[i];
+                        C.g1[i] = T.g1[i];
+                    } else {
+                        C.g0[i] = std::min(C.g0[i], T.g0[i]);
+                        C.g1[i] = std::max(C.g1[i], T.g1[i]);
+                    }
+                }
+                const bool active = T.g0[i] < T.g1[i];
+                T.g_off[i] = (long long)off;
+                if (active) off += (size_t)cn * T.H[i] * T.P[i];
+                T.r_off[i] = (long long)off;
+                if (active) off += (size_t)cn * T.H[i] * T.P[i];
+            }
+        }
+        P->tile_rows[t] = lv[t].gw[0];
+    }
+    for (int i = 0; i < SR_MAX_LEVELS; ++i) {
+        for (auto &T : P->tiles) {
+            if (i >= T.nl) continue;
+            P->max_w[i] = std::max(P->max_w[i], T.W[i]);
+            P->max_grows[i] = std::max(P->max_grows[i], T.g1[i] - T.g0[i]);
+            P->max_rrows[i] = std::max(P->max_rrows[i], T.r1[i] - T.r0[i]);
+        }
+        for (auto &C : P->classes) {
+            if (i >= C.nl) continue;
+            P->cmax_w[i] = std::max(P->cmax_w[i], C.W[i]);
+            P->cmax_rows[i] = std::max(P->cmax_rows[i], C.g1[i] - C.g0[i]);
+        }
+    }
+    P->arena_floats = off;
+
+    auto fail = [&](hipError_t e, const char *what) {
+        int code = (e == hipErrorOutOfMemory) ? SR_ERR_OOM : SR_ERR_HIP;
+        sr_set_error(code, "sr_blend_plan_create: %s: %s", what, hipGetErrorString(e));
+        sr_blend_plan_destroy(P);
+        return code;
+    };
+    hipError_t e;
+    if ((e = hipMalloc((void **)&P->d_arena, std::max<size_t>(off, 4) * sizeof(float))) != hipSuccess) return fail(e, "arena");
+    if ((e = hipMalloc((void **)&P->d_tiles, sizeof(TileDev) * n)) != hipSuccess) return fail(e, "tile table");
+    if ((e = hipMalloc((void **)&P->d_classes, sizeof(TileDev) * P->classes.size())) != hipSuccess) return fail(e, "class table");
+    if ((e = hipMalloc((void **)&P->d_srcs, sizeof(TileSrc) * n)) != hipSuccess) return fail(e, "src table");
+    if ((e = hipMalloc((void **)&P->d_luts, sizeof(float) * P->luts.size())) != hipSuccess) return fail(e, "luts");
+    if ((e = hipMemcpyAsync(P->d_tiles, P->tiles.data(), sizeof(TileDev) * n, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e, "upload");
+    if ((e = hipMemcpyAsync(P->d_classes, P->classes.data(), sizeof(TileDev) * P->classes.size(), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e, "upload");
+    if ((e = hipMemcpyAsync(P->d_luts, P->luts.data(), sizeof(float) * P->luts.size(), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e, "upload");
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(e, "sync");
+    *out = P;
+    return SR_OK;
+}
+
+int sr_blend_plan_tile_rows(const sr_blend_plan *plan, int t, int *r0, int *r1)
+{
+    if (!plan || t < 0 || t >= plan->n || !r0 || !r1) return sr_set_error(SR_ERR_INVALID_ARG, "sr_blend_plan_tile_rows: bad args");
+    *r0 = plan->tile_rows[t].a;
+    *r1 = plan->tile_rows[t].b;
+    return SR_OK;
+}
+
+int sr_blend_plan_workspace_bytes(const sr_blend_plan *plan, size_t *bytes)
+{
+    if (!plan || !bytes) return sr_set_error(SR_ERR_INVALID_ARG, "sr_blend_plan_workspace_bytes: bad args");
+    *bytes = plan->arena_floats * sizeof(float);
+    return SR_OK;
+}
+
+static int blend_impl(sr_blend_plan *P, bool lap, int dtype, void *const *h_d_tiles, const int64_t *h_strides,
+                      uint8_t *d_canvas, int64_t canvas_stride, float *d_canvas_f32)
+{
+    sr_ctx *ctx = P->ctx;
+    if (!h_d_tiles || !h_strides || !d_canvas) return sr_set_error(SR_ERR_INVALID_ARG, "blend: null argument");
+    if (dtype != SR_U8 && dtype != SR_F32) return sr_set_error(SR_ERR_INVALID_ARG, "blend: dtype must be SR_U8 or SR_F32");
+    if (canvas_stride < (int64_t)P->canvas_w * P->cn) return sr_set_error(SR_ERR_SHAPE, "blend: canvas stride too small");
+    const int es = dtype == SR_U8 ? 1 : 4;
+    std::vector<TileSrc> srcs(P->n);
+    for (int t = 0; t < P->n; ++t) {
+        if (!h_d_tiles[t] && !P->tile_rows[t].empty()) return sr_set_error(SR_ERR_INVALID_ARG, "blend: tile %d pointer is null", t);
+        if (h_strides[t] < (int64_t)P->tiles[t].w * P->cn * es) return sr_set_error(SR_ERR_SHAPE, "blend: tile %d stride too small", t);
+        srcs[t].p = h_d_tiles[t];
+        srcs[t].stride = h_strides[t];
+    }
+    HIPCHK(upload_small(ctx, P->d_srcs, srcs.data(), sizeof(TileSrc) * P->n));
+    const int rows = P->row_end - P->row_begin;
+    if (rows <= 0) return SR_OK;
+    dim3 block(64, 4);
+    if (lap && P->max_nl > 1) {
+        // weight pyramids: level 0 analytic (LUT) -> 1, then planar chain
+        for (int i = 0; i + 1 < P->max_nl; ++i) {
+            if (P->cmax_rows[i + 1] <= 0) continue;
+            ProfScope ps(ctx, "weight_down");
+            dim3 grid((P->cmax_w[i + 1] + 63) / 64, (P->cmax_rows[i + 1] + 3) / 4, (unsigned)P->classes.size());
+            if (i == 0) hipLaunchKernelGGL(k_down<SRC_LUT>, grid, block, 0, ctx->stream, P->d_classes, (const TileSrc *)nullptr, i, 1, P->d_arena, P->d_luts);
+            else hipLaunchKernelGGL(k_down<SRC_PLANAR>, grid, block, 0, ctx->stream, P->d_classes, (const TileSrc *)nullptr, i, 1, P->d_arena, P->d_luts);
+        }
+        // Gaussian chain of every tile
+        for (int i = 0; i + 1 < P->max_nl; ++i) {
+            if (P->max_grows[i + 1] <= 0) continue;
+            ProfScope ps(ctx, i == 0 ? "down_l0" : "down_l1p");
+            dim3 grid((P->max_w[i + 1] + 63) / 64, (P->max_grows[i + 1] + 3) / 4, P->n);
+            if (i == 0) {
+                if (dtype == SR_U8) hipLaunchKernelGGL(k_down<SRC_U8>, grid, block, 0, ctx->stream, P->d_tiles, P->d_srcs, i, P->cn, P->d_arena, P->d_luts);
+                else hipLaunchKernelGGL(k_down<SRC_F32>, grid, block, 0, ctx->stream, P->d_tiles, P->d_srcs, i, P->cn, P->d_arena, P->d_luts);
+            } else {
+                hipLaunchKernelGGL(k_down<SRC_PLANAR>, grid, block, 0, ctx->stream, P->d_tiles, P->d_srcs, i, P->cn, P->d_arena, P->d_luts);
+            }
+        }
+        int rc = check_launch("down chain");
+        if (rc) return rc;
+        // collapse chain: levels max_nl-1 .. 1
+        for (int i = P->max_nl - 1; i >= 1; --i) {
+            if (P->max_rrows[i] <= 0) continue;
+            ProfScope ps(ctx, "up_level");
+            dim3 grid((P->max_w[i] + 63) / 64, (P->max_rrows[i] + 3) / 4, P->n);
+            hipLaunchKernelGGL(k_up_level, grid, block, 0, ctx->stream, P->d_tiles, i, P->cn, P->d_arena);
+        }
+        rc = check_launch("up chain");
+        if (rc) return rc;
+    }
+    {
+        ProfScope ps(ctx, lap ? "final_gather" : "weighted_gather");
+        dim3 grid((P->canvas_w + 63) / 64, (rows + 3) / 4);
+#define LAUNCH_FINAL(DT, LAPV)                                                                                  \
+    hipLaunchKernelGGL((k_final<DT, LAPV>), grid, block, 0, ctx->stream, P->d_tiles, P->d_srcs, P->n, P->cn,     \
+                       P->d_arena, P->d_luts, d_canvas, (long long)canvas_stride, d_canvas_f32, P->canvas_w,     \
+                       P->row_begin, P->row_end)
+        if (lap) {
+            if (dtype == SR_U8) LAUNCH_FINAL(SRC_U8, true);
+            else LAUNCH_FINAL(SRC_F32, true);
+        } else {
+            if (dtype == SR_U8) LAUNCH_FINAL(SRC_U8, false);
+            else LAUNCH_FINAL(SRC_F32, false);
+        }
+#undef LAUNCH_FINAL
+    }
+    return check_launch("final gather");
+}
+
+int sr_laplacian_blend(sr_blend_plan *plan, int dtype, void *const *h_d_tiles, const int64_t *h_strides,
+                       uint8_t *d_canvas, int64_t canvas_stride, float *d_canvas_f32)
+{
+    if (!plan) return sr_set_error(SR_ERR_INVALID_ARG, "sr_laplacian_blend: null plan");
+    CTX_ENTER(plan->ctx);
+    return blend_impl(plan, true, dtype, h_d_tiles, h_strides, d_canvas, canvas_stride, d_canvas_f32);
+}
+
+int sr_weighted_blend(sr_blend_plan *plan, int dtype, void *const *h_d_tiles, const int64_t *h_strides,
+                      uint8_t *d_canvas, int64_t canvas_stride, float *d_canvas_f32)
+{
+    if (!plan) return sr_set_error(SR_ERR_INVALID_ARG, "sr_weighted_blend: null plan");
+    CTX_ENTER(plan->ctx);
+    return blend_impl(plan, false, dtype, h_d_tiles, h_strides, d_canvas, canvas_stride, d_canvas_f32);
+}
+
+static int fusion_host_impl(sr_ctx *ctx, bool lap, int dtype, const void *const *h_tiles, const sr_tile_rect *h_rects,
+                            int n, int cn, int canvas_h, int canvas_w, int levels, int weight_type, uint8_t *h_canvas,
+                            float *h_canvas_f32)
+{
+    if (!h_tiles || !h_rects || !h_canvas || n < 1) return sr_set_error(SR_ERR_INVALID_ARG, "fusion_host: bad arguments");
+    if (dtype != SR_U8 && dtype != SR_F32) return sr_set_error(SR_ERR_INVALID_ARG, "fusion_host: bad dtype");
+    sr_blend_plan *plan = nullptr;
+    int rc = sr_blend_plan_create(ctx, h_rects, n, cn, canvas_h, canvas_w, levels, weight_type, 0, canvas_h, &plan);
+    if (rc) return rc;
+    const int es = dtype == SR_U8 ? 1 : 4;
+    std::vector<void *> d_tiles(n, nullptr);
+    std::vector<int64_t> strides(n);
+    void *d_canvas = nullptr, *d_f32 = nullptr;
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(ctx->stream);
+        for (auto p : d_tiles)
+            if (p) (void)hipFree(p);
+        if (d_canvas) (void)hipFree(d_canvas);
+        if (d_f32) (void)hipFree(d_f32);
+        sr_blend_plan_destroy(plan);
+    };
+    for (int t = 0; t < n && rc == SR_OK; ++t) {
+        const size_t bytes = (size_t)h_rects[t].h * h_rects[t].w * cn * es;
+        strides[t] = (int64_t)h_rects[t].w * cn * es;
+        hipError_t e = hipMalloc(&d_tiles[t], bytes);
+        if (e != hipSuccess) rc = sr_set_error(e == hipErrorOutOfMemory ? SR_ERR_OOM : SR_ERR_HIP, "fusion_host: hipMalloc: %s", hipGetErrorString(e));
+        else if ((e = hipMemcpyAsync(d_tiles[t], h_tiles[t], bytes, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+            rc = sr_set_error(SR_ERR_HIP, "fusion_host: H2D: %s", hipGetErrorString(e));
+    }
+    const size_t cbytes = (size_t)canvas_h * canvas_w * cn;
+    if (rc == SR_OK) {
+        hipError_t e = hipMalloc(&d_canvas, cbytes);
+        if (e != hipSuccess) rc = sr_set_error(e == hipErrorOutOfMemory ? SR_ERR_OOM : SR_ERR_HIP, "fusion_host: hipMalloc: %s", hipGetErrorString(e));
+    }
+    if (rc == SR_OK && h_canvas_f32) {
+        hipError_t e = hipMalloc(&d_f32, cbytes * sizeof(float));
+        if (e != hipSuccess) rc = sr_set_error(e == hipErrorOutOfMemory ? SR_ERR_OOM : SR_ERR_HIP, "fusion_host: hipMalloc: %s", hipGetErrorString(e));
+    }
+    if (rc == SR_OK)
+        rc = blend_impl(plan, lap, dtype, d_tiles.data(), strides.data(), (uint8_t *)d_canvas, (int64_t)canvas_w * cn, (float *)d_f32);
+    if (rc == SR_OK) {
+        hipError_t e = hipMemcpyAsync(h_canvas, d_canvas, cbytes, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && h_canvas_f32) e = hipMemcpyAsync(h_canvas_f32, d_f32, cbytes * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = sr_set_error(SR_ERR_HIP, "fusion_host: D2H: %s", hipGetErrorString(e));
+    }
+    cleanup();
+    return rc;
+}
+
+int sr_laplacian_fusion_host(sr_ctx *ctx, int dtype, const void *const *h_tiles, const sr_tile_rect *h_rects, int n,
+                             int cn, int canvas_h, int canvas_w, int levels, int weight_type, uint8_t *h_canvas,
+                             float *h_canvas_f32)
+{
+    CTX_ENTER(ctx);
+    return fusion_host_impl(ctx, true, dtype, h_tiles, h_rects, n, cn, canvas_h, canvas_w, levels, weight_type, h_canvas,
+                            h_canvas_f32);
+}
+
+int sr_weighted_fusion_host(sr_ctx *ctx, int dtype, const void *const *h_tiles, const sr_tile_rect *h_rects, int n,
+                            int cn, int canvas_h, int canvas_w, int weight_type, uint8_t *h_canvas, float *h_canvas_f32)
+{
+    CTX_ENTER(ctx);
+    return fusion_host_impl(ctx, false, dtype, h_tiles, h_rects, n, cn, canvas_h, canvas_w, 1, weight_type, h_canvas,
+                            h_canvas_f32);
+}
+
+int sr_feather_merge(sr_ctx *ctx, const sr_merge_tile *, int, void *const *, const int64_t *, int, uint8_t *, int64_t,
+                     int, int)
+{
+    CTX_ENTER(ctx);
+    return sr_set_error(SR_ERR_UNSUPPORTED, "sr_feather_merge: not built yet");
+}
+
+// ---- metrics ------------------------------------------------------------------------------------------
+int sr_sse_u8_async(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uint8_t *d_b, int64_t stride_b, int h,
+                    int64_t rowlen, uint64_t *d_sse)
+{
+    CTX_ENTER(ctx);
+    if (!d_a || !d_b || !d_sse || h < 0 || rowlen < 0) return sr_set_error(SR_ERR_INVALID_ARG, "sr_sse_u8: bad arguments");
+    HIPCHK(hipMemsetAsync(d_sse, 0, sizeof(uint64_t), ctx->stream));
+    if (h == 0 || rowlen == 0) return SR_OK;
+    const bool dense = stride_a == rowlen && stride_b == rowlen && ((uintptr_t)d_a % 16 == 0) && ((uintptr_t)d_b % 16 == 0);
+    {
+        ProfScope ps(ctx, "psnr_sse");
+        if (dense) {
+            const size_t total = (size_t)h * (size_t)rowlen;
+            const size_t nvec = total / 16;
+            const int ntail = (int)(total - nvec * 16);
+            const int blocks = (int)std::min<size_t>((nvec + 255) / 256 + 1, 256 * 16);
+            hipLaunchKernelGGL(k_sse_flat, dim3(blocks), dim3(256), 0, ctx->stream, (const uint4 *)d_a, (const uint4 *)d_b, nvec,
+                               d_a + nvec * 16, d_b + nvec * 16, ntail, (unsigned long long *)d_sse);
+        } else {
+            const int gx = (int)std::min<int64_t>((rowlen + 255) / 256, 64);
+            const int gy = std::min(h, 1024);
+            hipLaunchKernelGGL(k_sse_rows, dim3(gx, gy), dim3(256), 0, ctx->stream, d_a, (long long)stride_a, d_b,
+                               (long long)stride_b, h, (long long)rowlen, (unsigned long long *)d_sse);
+        }
+    }
+    return check_launch("psnr_sse");
+}
+
+int sr_sse_u8(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uint8_t *d_b, int64_t stride_b, int h,
+              int64_t rowlen, uint64_t *h_sse)
+{
+    CTX_ENTER(ctx);
+    if (!h_sse) return sr_set_error(SR_ERR_INVALID_ARG, "sr_sse_u8: null result");
+    void *scr = nullptr;
+    int rc = ctx_scratch(ctx, 64, &scr);
+    if (rc) return rc;
+    rc = sr_sse_u8_async(ctx, d_a, stride_a, d_b, stride_b, h, rowlen, (uint64_t *)scr);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(h_sse, scr, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(stream_sync(ctx));
+    return SR_OK;
+}
+
+static int ssim_params(int h, int w, int cn, int mode, int gray_shift, double data_range, int row_begin, int row_end,
+                       SsimParams *P)
+{
+    if (h < 1 || w < 1 || (cn != 1 && cn != 3)) return sr_set_error(SR_ERR_INVALID_ARG, "sr_ssim_u8: need h,w >= 1 and 1 or 3 channels");
+    if (gray_shift != 14 && gray_shift != 15) return sr_set_error(SR_ERR_INVALID_ARG, "sr_ssim_u8: gray_shift must be 14 or 15");
+    memset(P, 0, sizeof(*P));
+    P->h = h;
+    P->w = w;
+    P->cn = cn;
+    P->shift = gray_shift;
+    int pad;
+    if (mode == SR_SSIM_UNIFORM7) {
+        P->klen = 7;
+        pad = 3;
+        P->cov_norm = 49.0 / 48.0;
+        P->bmode = PAD_REFLECT;
+        for (int i = 0; i < 7; ++i) P->k[i] = 1.0 / 7.0;
+    } else if (mode == SR_SSIM_GAUSS11 || mode == SR_SSIM_SIMPLE) {
+        P->klen = 11;
+        P->cov_norm = 1.0;
+        double s = 0;
+        if (mode == SR_SSIM_GAUSS11) {
+            pad = 5;
+            P->bmode = PAD_REFLECT;
+            for (int i = 0; i < 11; ++i) {
+                const double x = i - 5;
+                P->k[i] = std::exp(-0.5 / (1.5 * 1.5) * x * x);
+                s += P->k[i];
+            }
+        } else {
+            pad = 0;
+            P->bmode = PAD_MIRROR;
+            data_range = 255.0;
+            for (int i = 0; i < 11; ++i) {
+                const double x = i - 5.0;
+                P->k[i] = std::exp(-(x * x) / (2.0 * 1.5 * 1.5));
+                s += P->k[i];
+            }
+        }
+        for (int i = 0; i < 11; ++i) P->k[i] /= s;
+    } else {
+        return sr_set_error(SR_ERR_INVALID_ARG, "sr_ssim_u8: unknown mode %d", mode);
+    }
+    P->rad = P->klen / 2;
+    if (h <= 2 * pad || w <= 2 * pad)
+        return sr_set_error(SR_ERR_SHAPE, "sr_ssim_u8: image %dx%d smaller than the %d-tap window", w, h, P->klen);
+    P->c1 = (0.01 * data_range) * (0.01 * data_range);
+    P->c2 = (0.03 * data_range) * (0.03 * data_range);
+    P->vy0 = std::max(pad, row_begin);
+    P->vy1 = std::min(h - pad, row_end);
+    P->vx0 = pad;
+    P->vx1 = w - pad;
+    return SR_OK;
+}
+
+int sr_ssim_u8_async(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uint8_t *d_b, int64_t stride_b, int h,
+                     int w, int cn, int mode, int gray_shift, double data_range, int row_begin, int row_end,
+                     double *d_sum, uint64_t *h_count)
+{
+    CTX_ENTER(ctx);
+    if (!d_a || !d_b || !d_sum || !h_count) return sr_set_error(SR_ERR_INVALID_ARG, "sr_ssim_u8: null argument");
+    SsimParams P;
+    int rc = ssim_params(h, w, cn, mode, gray_shift, data_range, row_begin, row_end, &P);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(d_sum, 0, sizeof(double), ctx->stream));
+    if (P.vy0 >= P.vy1) {
+        *h_count = 0;
+        return SR_OK;
+    }
+    *h_count = (uint64_t)(P.vy1 - P.vy0) * (uint64_t)(P.vx1 - P.vx0);
+    const int gx = (P.vx1 - P.vx0 + SS_TX - 1) / SS_TX, gy = (P.vy1 - P.vy0 + SS_TY - 1) / SS_TY;
+    void *scr = nullptr;
+    rc = ctx_scratch(ctx, sizeof(double) * (size_t)gx * gy + 64, &scr);
+    if (rc) return rc;
+    double *partials = (double *)((char *)scr + 64);
+    {
+        ProfScope ps(ctx, mode == SR_SSIM_UNIFORM7 ? "ssim_uniform7" : (mode == SR_SSIM_GAUSS11 ? "ssim_gauss11" : "ssim_simple"));
+        hipLaunchKernelGGL(k_ssim, dim3(gx, gy), dim3(256), 0, ctx->stream, d_a, (long long)stride_a, d_b,
+                           (long long)stride_b, P, partials);
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, (const double *)partials, gx * gy, d_sum);
+    }
+    return check_launch("ssim");
+}
+
+int sr_ssim_u8(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uint8_t *d_b, int64_t stride_b, int h, int w,
+               int cn, int mode, int gray_shift, double data_range, int row_begin, int row_end, double *h_sum,
+               uint64_t *h_count)
+{
+    CTX_ENTER(ctx);
+    if (!h_sum || !h_count) return sr_set_error(SR_ERR_INVALID_ARG, "sr_ssim_u8: null result");
+    void *res = nullptr;
+    HIPCHK(hipMalloc(&res, 64));
+    int rc = sr_ssim_u8_async(ctx, d_a, stride_a, d_b, stride_b, h, w, cn, mode, gray_shift, data_range, row_begin,
+                              row_end, (double *)res, h_count);
+    if (rc == SR_OK) {
+        hipError_t e = hipMemcpyAsync(h_sum, res, sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = sr_set_error(SR_ERR_HIP, "sr_ssim_u8: D2H: %s", hipGetErrorString(e));
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(res);
+    return rc;
+}
+
+int sr_rgb2gray_u8(sr_ctx *ctx, const uint8_t *d_rgb, int64_t stride, int h, int w, int gray_shift, uint8_t *d_gray,
+                   int64_t gray_stride)
+{
+    CTX_ENTER(ctx);
+    if (!d_rgb || !d_gray || h < 1 || w < 1 || (gray_shift != 14 && gray_shift != 15))
+        return sr_set_error(SR_ERR_INVALID_ARG, "sr_rgb2gray_u8: bad arguments");
+    {
+        ProfScope ps(ctx, "rgb2gray");
+        dim3 grid((w + 63) / 64, (h + 3) / 4), block(64, 4);
+        hipLaunchKernelGGL(k_rgb2gray, grid, block, 0, ctx->stream, d_rgb, (long long)stride, h, w, gray_shift, d_gray,
+                           (long long)gray_stride);
+    }
+    return check_launch("rgb2gray");
+}
+
+int sr_resize_cubic_window_u8(sr_ctx *ctx, const uint8_t *d_src, int64_t src_stride, int h, int w, int cn, int dh,
+                              int dw, int x0, int y0, int ww, int wh, uint8_t *d_dst, int64_t dst_stride)
+{
+    CTX_ENTER(ctx);
+    if (!d_src || !d_dst || h < 1 || w < 1 || dh < 1 || dw < 1 || cn < 1 || cn > 4)
+        return sr_set_error(SR_ERR_INVALID_ARG, "sr_resize_cubic_u8: bad arguments");
+    if (x0 < 0 || y0 < 0 || ww < 1 || wh < 1 || x0 + ww > dw || y0 + wh > dh)
+        return sr_set_error(SR_ERR_SHAPE, "sr_resize_cubic_u8: window outside the %dx%d result", dw, dh);
+    std::vector<CubicTab> xt, yt;
+    cubic_table(w, dw, xt);
+    cubic_table(h, dh, yt);
+    void *scr = nullptr;
+    int rc = ctx_scratch(ctx, sizeof(CubicTab) * ((size_t)dw + dh), &scr);
+    if (rc) return rc;
+    CubicTab *dx = (CubicTab *)scr, *dy = dx + dw;
+    HIPCHK(upload_small(ctx, dx, xt.data(), sizeof(CubicTab) * dw));
+    HIPCHK(upload_small(ctx, dy, yt.data(), sizeof(CubicTab) * dh));
+    {
+        ProfScope ps(ctx, "resize_cubic");
+        dim3 grid((ww + 63) / 64, (wh + 3) / 4), block(64, 4);
+        hipLaunchKernelGGL(k_resize_cubic, grid, block, 0, ctx->stream, d_src, (long long)src_stride, h, w, cn,
+                           (const CubicTab *)dx, (const CubicTab *)dy, x0, y0, ww, wh, d_dst, (long long)dst_stride);
+    }
+    return check_launch("resize_cubic");
+}
+
+int sr_resize_cubic_u8(sr_ctx *ctx, const uint8_t *d_src, int64_t src_stride, int h, int w, int cn, uint8_t *d_dst,
+                       int64_t dst_stride, int dh, int dw)
+{
+    return sr_resize_cubic_window_u8(ctx, d_src, src_stride, h, w, cn, dh, dw, 0, 0, dw, dh, d_dst, dst_stride);
+}
+
+}  // extern "C"

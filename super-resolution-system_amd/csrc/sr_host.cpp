@@ -1,0 +1,211 @@
+// sr_host.cpp -- host-only part of the C ABI: error strings, the integer tile bookkeeping of
+// tiling_module.py / main.py, the weight LUT and the strip-window planner.  No HIP calls.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <utility>
+
+#include "sr_internal.h"
+
+static thread_local char g_err[512] = "";
+
+int sr_set_error(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" {
+
+int sr_version(void) { return 100; }
+
+const char *sr_last_error(void) { return g_err; }
+
+// tiling_module.py:572-608.  np.ceil((dim - ov) / step) on a float64 quotient.
+int sr_tile_plan(int image_w, int image_h, int block_size, int overlap_px, int *n_tiles, int *h_xywh,
+                 int cap)
+{
+    if (!n_tiles) return sr_set_error(SR_ERR_INVALID_ARG, "sr_tile_plan: n_tiles is null");
+    if (image_w <= 0 || image_h <= 0 || block_size <= 0 || overlap_px < 0 || overlap_px >= block_size)
+        return sr_set_error(SR_ERR_INVALID_ARG, "sr_tile_plan: bad geometry %dx%d block %d overlap %d",
+                            image_w, image_h, block_size, overlap_px);
+    const int step = block_size - overlap_px;
+    const int nx = std::max(1, (int)std::ceil((double)(image_w - overlap_px) / (double)step));
+    const int ny = std::max(1, (int)std::ceil((double)(image_h - overlap_px) / (double)step));
+    *n_tiles = nx * ny;
+    if (!h_xywh) return SR_OK;
+    if (cap < nx * ny) return sr_set_error(SR_ERR_SHAPE, "sr_tile_plan: need room for %d tiles", nx * ny);
+    int k = 0;
+    for (int ty = 0; ty < ny; ++ty)
+        for (int tx = 0; tx < nx; ++tx) {
+            const int x = tx * step, y = ty * step;
+            h_xywh[k++] = x;
+            h_xywh[k++] = y;
+            h_xywh[k++] = std::min(block_size, image_w - x);
+            h_xywh[k++] = std::min(block_size, image_h - y);
+        }
+    return SR_OK;
+}
+
+// tiling_module.py:610-646, including the last row / column override.
+int sr_tile_overlaps(int x, int y, int w, int h, int image_w, int image_h, int block_size, int overlap_px,
+                     int *h_tblr)
+{
+    if (!h_tblr) return sr_set_error(SR_ERR_INVALID_ARG, "sr_tile_overlaps: output is null");
+    int top = y > 0 ? overlap_px : 0;
+    int left = x > 0 ? overlap_px : 0;
+    int bottom = (y + h < image_h) ? overlap_px : 0;
+    int right = (x + w < image_w) ? overlap_px : 0;
+    if (y + block_size >= image_h) bottom = std::max(0, block_size - (image_h - y) - top);
+    if (x + block_size >= image_w) right = std::max(0, block_size - (image_w - x) - left);
+    h_tblr[0] = top;
+    h_tblr[1] = bottom;
+    h_tblr[2] = left;
+    h_tblr[3] = right;
+    return SR_OK;
+}
+
+// tiling_module.py:786-823: dict keyed by (global_x, global_y); later duplicates overwrite.
+int sr_tile_neighbors(const int *h_xywh, int n, int block_size, int overlap_px, int *h_nbr)
+{
+    if (!h_xywh || !h_nbr || n < 0) return sr_set_error(SR_ERR_INVALID_ARG, "sr_tile_neighbors: bad args");
+    const int step = block_size - overlap_px;
+    std::map<std::pair<int, int>, int> index;
+    for (int i = 0; i < n; ++i) index[{h_xywh[4 * i], h_xywh[4 * i + 1]}] = i;
+    auto find = [&](int x, int y) {
+        auto it = index.find({x, y});
+        return it == index.end() ? -1 : it->second;
+    };
+    for (int i = 0; i < n; ++i) {
+        const int x = h_xywh[4 * i], y = h_xywh[4 * i + 1];
+        h_nbr[4 * i + 0] = find(x, y - step);
+        h_nbr[4 * i + 1] = find(x, y + step);
+        h_nbr[4 * i + 2] = find(x - step, y);
+        h_nbr[4 * i + 3] = find(x + step, y);
+    }
+    return SR_OK;
+}
+
+// main.py:168-184 (float aspect compare, int() truncation)
+int sr_target_size(int width, int height, int preset_mp, int *out_w, int *out_h)
+{
+    if (width <= 0 || height <= 0 || !out_w || !out_h)
+        return sr_set_error(SR_ERR_INVALID_ARG, "sr_target_size: bad args");
+    int tw, th;
+    switch (preset_mp) {
+    case 100: tw = 12245; th = 8163; break;
+    case 150: tw = 15000; th = 10000; break;
+    case 200: tw = 17320; th = 11547; break;
+    default: return sr_set_error(SR_ERR_INVALID_ARG, "sr_target_size: unknown preset %dMP", preset_mp);
+    }
+    const double aspect = (double)width / (double)height;
+    if (aspect > (double)tw / (double)th) th = (int)((double)tw / aspect);
+    else tw = (int)((double)th * aspect);
+    *out_w = tw;
+    *out_h = th;
+    return SR_OK;
+}
+
+// blending_module.py:547-559 in float64, cast to fp32, tabulated by integer edge distance.
+int sr_weight_lut(int fw, int weight_type, float *h_lut)
+{
+    if (fw < 1 || !h_lut)
+        return sr_set_error(SR_ERR_INVALID_ARG,
+                            "sr_weight_lut: feather width %d (tile min side < 8 gives the reference a "
+                            "zero feather width and NaN weights)", fw);
+    for (int d = 0; d <= fw; ++d) {
+        double nd = (double)d / (double)fw;
+        nd = std::min(1.0, std::max(0.0, nd));
+        double v;
+        if (weight_type == SR_W_COSINE) v = 0.5 * (1 - std::cos(M_PI * nd));
+        else if (weight_type == SR_W_SIGMOID) v = 1 / (1 + std::exp(-10 * (nd - 0.5)));
+        else v = nd;
+        h_lut[d] = (float)v;
+    }
+    return SR_OK;
+}
+
+double sr_psnr_from_sse(uint64_t sse, uint64_t count, double data_range)
+{
+    if (count == 0) return NAN;
+    const double mse = (double)sse / (double)count;
+    if (mse == 0.0) return INFINITY;
+    return 10.0 * std::log10((data_range * data_range) / mse);
+}
+
+}  // extern "C"
+
+// build_gaussian_pyramid's stop rule (blending_module.py:248-252)
+void sr_level_dims(int h, int w, int levels, int *nl, int *H, int *W)
+{
+    int k = 1;
+    H[0] = h;
+    W[0] = w;
+    while (k < levels && k < SR_MAX_LEVELS && H[k - 1] >= 2 && W[k - 1] >= 2) {
+        H[k] = (H[k - 1] + 1) / 2;
+        W[k] = (W[k - 1] + 1) / 2;
+        ++k;
+    }
+    *nl = k;
+}
+
+static SrWin hull(SrWin p, SrWin q)
+{
+    if (p.empty()) return q;
+    if (q.empty()) return p;
+    return {std::min(p.a, q.a), std::max(p.b, q.b)};
+}
+
+// destination rows d of a pyrUp -> source rows it reads (low edge reflect-101, high edge clamp)
+static SrWin need_up(SrWin d, int hs)
+{
+    if (d.empty()) return {0, 0};
+    if (hs < 8) return {0, hs};
+    int lo = d.a / 2 - 1, hi = (d.b - 1) / 2 + 1;
+    if (lo < 0) {
+        lo = 0;
+        hi = std::max(hi, 1);
+    }
+    hi = std::min(hi, hs - 1);
+    return {lo, hi + 1};
+}
+
+// destination rows d of a pyrDown -> source rows it reads (reflect-101 both ends)
+static SrWin need_down(SrWin d, int hs)
+{
+    if (d.empty()) return {0, 0};
+    if (hs < 8) return {0, hs};
+    int lo = 2 * d.a - 2, hi = 2 * (d.b - 1) + 2;
+    if (lo < 0) {
+        lo = 0;
+        hi = std::max(hi, 2);
+    }
+    if (hi > hs - 1) {
+        lo = std::min(lo, hs - 3);
+        hi = hs - 1;
+    }
+    return {std::max(lo, 0), hi + 1};
+}
+
+void sr_plan_windows(int tile_h, int tile_w, int tile_y, int levels, int row_begin, int row_end,
+                     int canvas_h, SrTileLevels *out)
+{
+    SrTileLevels &L = *out;
+    sr_level_dims(tile_h, tile_w, levels, &L.nl, L.H, L.W);
+    const int lo = std::max(std::max(row_begin, 0) - tile_y, 0);
+    const int hi = std::min(std::min(row_end, canvas_h) - tile_y, tile_h);
+    L.cw = {lo, hi};
+    for (int i = 0; i < SR_MAX_LEVELS; ++i) L.gw[i] = L.rw[i] = {0, 0};
+    if (L.cw.empty()) {
+        L.cw = {0, 0};
+        return;
+    }
+    L.rw[0] = L.cw;
+    for (int i = 1; i < L.nl; ++i) L.rw[i] = need_up(L.rw[i - 1], L.H[i]);
+    L.gw[L.nl - 1] = L.rw[L.nl - 1];
+    for (int i = L.nl - 2; i >= 0; --i) L.gw[i] = hull(L.rw[i], need_down(L.gw[i + 1], L.H[i]));
+}

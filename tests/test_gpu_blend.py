@@ -1,0 +1,157 @@
+"""GPU parity: HIP pyramid / blend path vs the CPU oracle (oracle/sr_oracle.c), through the C ABI.
+
+Bar: the fp32 canvas before quantisation is bit-exact with the oracle (same expression order,
+no FMA contraction); the u8 canvas is identical.  The OpenCV-defined semantics themselves are
+'parity unpinned' (see oracle header)."""
+import numpy as np
+import pytest
+
+from oracle import oracle_c as oc
+from oracle import oracle_np as onp
+
+pytestmark = pytest.mark.gpu
+
+
+def _tiles(rng, n, h, w, cn=3, dtype=np.uint8):
+    out = []
+    for i in range(n):
+        yy, xx = np.mgrid[0:h, 0:w]
+        base = 128 + 64 * np.sin(xx / 37.0 + i) + 48 * np.cos(yy / 23.0 + 0.5 * i)
+        img = base[..., None] + rng.integers(-12, 13, (h, w, cn)) + 7 * i
+        img = np.clip(img, 0, 255)
+        out.append(img.astype(dtype) if cn > 1 else img[..., 0].astype(dtype))
+    return out
+
+
+@pytest.mark.parametrize("shape", [(37, 53, 3), (64, 64, 3), (130, 96), (2, 2, 3), (9, 2, 3), (301, 517, 3)])
+def test_pyr_down_up_dense(ctx, rng, shape):
+    a = rng.uniform(0, 255, shape).astype(np.float32)
+    d_ref = oc.pyr_down(a)
+    d_gpu = ctx.pyr_down_np(a)
+    assert d_gpu.shape == d_ref.shape
+    assert np.array_equal(d_gpu, d_ref)
+    u_ref = oc.pyr_up(d_ref, a.shape[:2])
+    assert np.array_equal(ctx.pyr_up_np(d_ref, a.shape[:2]), u_ref)
+    assert np.array_equal(ctx.pyr_up_np(d_ref, a.shape[:2], a, "sub"), a - u_ref)
+    assert np.array_equal(ctx.pyr_up_np(d_ref, a.shape[:2], a, "add"), u_ref + a)
+
+
+def test_pyr_up_rejects_bad_size(ctx):
+    import _native
+    with pytest.raises(_native.SrShapeError):
+        ctx.pyr_up_np(np.zeros((4, 4), np.float32), (9, 8))
+
+
+GRIDS = [
+    # (tile_h, tile_w, rows, cols, overlap, levels, weight)
+    (96, 130, 2, 2, 30, 6, "cosine"),
+    (64, 64, 1, 3, 16, 6, "linear"),
+    (97, 61, 3, 2, 20, 4, "sigmoid"),
+    (512, 512, 2, 2, 100, 6, "cosine"),   # blending_module.py:1774-1814 demo geometry (924^2 canvas)
+    (40, 200, 2, 1, 8, 1, "cosine"),      # levels = 1: R0 = G0 * W0
+]
+
+
+@pytest.mark.parametrize("th,tw,rows,cols,ov,levels,wt", GRIDS)
+def test_laplacian_fusion_grid(ctx, rng, th, tw, rows, cols, ov, levels, wt):
+    tiles = _tiles(rng, rows * cols, th, tw)
+    pos = [((i // cols) * (th - ov), (i % cols) * (tw - ov)) for i in range(rows * cols)]
+    shape = (rows * th - (rows - 1) * ov, cols * tw - (cols - 1) * ov)
+    ref_u8, ref_f = oc.laplacian_fusion(tiles, pos, shape, levels, wt, return_float=True)
+    out_u8, out_f = ctx.fusion_np(tiles, pos, shape, levels, wt, laplacian=True, return_float=True)
+    assert np.array_equal(out_f, ref_f), float(np.nanmax(np.abs(out_f - ref_f)))
+    assert np.array_equal(out_u8, ref_u8)
+
+
+def test_laplacian_fusion_ragged_and_cropped(ctx, rng):
+    """Different tile sizes, arbitrary positions, a hole (sum w = 0) and a tile sticking out of the
+    canvas (cropped like blending_module.py:477-484)."""
+    sizes = [(80, 120), (100, 90), (64, 150), (90, 90)]
+    pos = [(0, 0), (10, 100), (70, 20), (75, 160)]
+    tiles = [_tiles(rng, 1, h, w)[0] for h, w in sizes]
+    shape = (150, 230)
+    ref_u8, ref_f = oc.laplacian_fusion(tiles, pos, shape, 6, "cosine", return_float=True)
+    out_u8, out_f = ctx.fusion_np(tiles, pos, shape, 6, "cosine", return_float=True)
+    assert np.array_equal(out_f, ref_f)
+    assert np.array_equal(out_u8, ref_u8)
+
+
+def test_laplacian_fusion_gray_and_float_tiles(ctx, rng):
+    tiles = _tiles(rng, 2, 72, 88, cn=1)
+    pos = [(0, 0), (0, 60)]
+    ref = oc.laplacian_fusion(tiles, pos, (72, 148), 5, "cosine", return_float=True)
+    out = ctx.fusion_np(tiles, pos, (72, 148), 5, "cosine", return_float=True)
+    assert np.array_equal(out[1], ref[1]) and np.array_equal(out[0], ref[0])
+    ftiles = [t.astype(np.float32) * 0.75 + 3.25 for t in _tiles(rng, 2, 72, 88)]
+    ref = oc.laplacian_fusion(ftiles, pos, (72, 148), 6, "cosine", return_float=True)
+    out = ctx.fusion_np(ftiles, pos, (72, 148), 6, "cosine", return_float=True)
+    assert np.array_equal(out[1], ref[1]) and np.array_equal(out[0], ref[0])
+
+
+@pytest.mark.parametrize("wt", ["cosine", "linear", "sigmoid"])
+def test_weighted_average_fusion(ctx, rng, wt):
+    tiles = _tiles(rng, 4, 96, 130)
+    pos = [(0, 0), (0, 100), (70, 0), (70, 100)]
+    ref = oc.weighted_average_fusion(tiles, pos, (166, 230), wt, return_float=True)
+    out = ctx.fusion_np(tiles, pos, (166, 230), 6, wt, laplacian=False, return_float=True)
+    assert np.array_equal(out[1], ref[1]) and np.array_equal(out[0], ref[0])
+
+
+def test_fusion_rejects_tiny_tile(ctx):
+    with pytest.raises(ValueError):
+        ctx.fusion_np([np.zeros((6, 40, 3), np.uint8)], [(0, 0)], (6, 40), 6, "cosine")
+
+
+def test_golden_blend_fixture(ctx):
+    """Committed fixture (restatement-derived, OpenCV-unverified): see tests/golden/README.md."""
+    import os
+    p = os.path.join(os.path.dirname(__file__), "golden", "blend_small.npz")
+    z = np.load(p)
+    tiles = [z[f"tile{i}"] for i in range(int(z["n"]))]
+    pos = [tuple(p) for p in z["pos"]]
+    out_u8, out_f = ctx.fusion_np(tiles, pos, tuple(z["shape"]), int(z["levels"]), "cosine", return_float=True)
+    assert np.array_equal(out_u8, z["canvas_u8"])
+    np.testing.assert_allclose(out_f, z["canvas_f32"], rtol=1e-6, atol=1e-5)
+
+
+def test_strip_windows_bit_identical(ctx, rng):
+    """Multi-GPU decomposition on one GPU: each 'virtual rank' blends only its canvas strip from
+    tiles whose rows outside sr_blend_plan_tile_rows are poisoned; strips must equal the monolithic
+    result bit for bit."""
+    import _native
+    th, tw, rows, cols, ov = 300, 260, 3, 2, 60
+    tiles = _tiles(rng, rows * cols, th, tw)
+    rects = [((i % cols) * (tw - ov), (i // cols) * (th - ov), tw, th) for i in range(rows * cols)]
+    H, W = rows * th - (rows - 1) * ov, cols * tw - (cols - 1) * ov
+    pos = [(r[1], r[0]) for r in rects]
+    ref_u8, ref_f = oc.laplacian_fusion(tiles, pos, (H, W), 6, "cosine", return_float=True)
+    n_ranks = 5
+    bounds = [H * r // n_ranks for r in range(n_ranks + 1)]
+    canvas = ctx.alloc(H * W * 3)
+    canvas_f = ctx.alloc(H * W * 3 * 4)
+    ctx.memset(canvas.ptr, 0, H * W * 3)
+    for r in range(n_ranks):
+        plan = _native.BlendPlan(ctx, rects, 3, H, W, 6, "cosine", bounds[r], bounds[r + 1])
+        bufs, ptrs = [], []
+        for t, tile in enumerate(tiles):
+            a, b = plan.tile_rows(t)
+            poisoned = np.full_like(tile, 0xAA)
+            poisoned[a:b] = tile[a:b]
+            if a < b:
+                assert b - a <= th
+            bufs.append(ctx.upload(poisoned))
+            ptrs.append(bufs[-1].ptr)
+        plan.blend(ptrs, [tw * 3] * len(tiles), canvas.ptr, W * 3, _native.SR_U8, canvas_f.ptr)
+        ctx.sync()
+        plan.close()
+        for b_ in bufs:
+            b_.free()
+    out_u8 = ctx.download(canvas.ptr, (H, W, 3), np.uint8)
+    out_f = ctx.download(canvas_f.ptr, (H, W, 3), np.float32)
+    assert np.array_equal(out_f, ref_f)
+    assert np.array_equal(out_u8, ref_u8)
+    # halo is bounded: a strip in the middle must not need whole tiles
+    plan = _native.BlendPlan(ctx, [(0, 0, 2000, 3000)], 3, 3000, 2000, 6, "cosine", 1400, 1600)
+    a, b = plan.tile_rows(0)
+    assert 1400 - 160 <= a <= 1400 and 1600 <= b <= 1600 + 160
+    plan.close()
