@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py -- megapixels/sec of tile + blend + QA on a synthetic 720p -> 200 MP job (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 200MP|150MP|100MP|4MP]
+
+One process per GPU (N > 1: launched by torch.distributed.run, RCCL over xGMI).  A "step" is one
+pass of the hot path over one synthetic image: overlap-tile extract of the 5x5 tile grid from the
+device-resident SR output, [exchange of tile rows between tile owners and strip owners],
+Laplacian-pyramid blend of the canvas strips, PSNR + SSIM (uniform-7, Gaussian-11 cropped,
+Gaussian-11 full-frame) of the canvas against the reference upscale, one all-reduce of the metric
+partial sums.  N > 1 splits the SAME image over the ranks (strong scaling).
+
+Prints ONE JSON line (rank 0).  ``value`` = canvas megapixels / max-over-ranks wall time per step,
+inputs already resident in HBM.  ``roofline`` describes the dominant kernel (HIP-event time measured
+here, on the stream the kernels run on); ``cpu_baseline`` is the CPU oracle (oracle/sr_oracle.c,
+OpenMP) timed on this node's host cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "super-resolution-system_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def synthetic_source(w: int = 1080, h: int = 720, seed: int = 20260313, noise_seed_offset: int = 0) -> np.ndarray:
+    """smooth field + integer noise, 3:2 so the 200 MP preset is reached."""
+    rng = np.random.default_rng(seed + noise_seed_offset)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    chans = []
+    for c in range(3):
+        chans.append(128 + 64 * np.sin(xx / 37.0 + 0.7 * c) + 48 * np.cos(yy / 23.0 + 1.3 * c))
+    img = np.stack(chans, axis=-1) + rng.integers(-12, 13, (h, w, 3))
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def algorithmic_bytes(geo) -> dict:
+    """Bytes each kernel family must move per step (DESIGN.md 'kernels and their rooflines')."""
+    n, m = geo.tile_pixels, geo.canvas_pixels
+    s14 = sum(4.0 ** -i for i in range(1, 5))
+    s25 = sum(4.0 ** -i for i in range(2, 6))
+    return {
+        "tile_extract": 6.0 * n,                                   # 3 B read + 3 B write per tile px
+        "down_l0": 6.0 * n,                                        # u8 in (3) + G1 out (12/4)
+        "down_l1p": (12.0 * s14 + 12.0 * s25) * n,                 # G1..G4 in, G2..G5 out
+        "up_level": (34.0 * s14 + 28.0 * 4.0 ** -5) * n,           # G_i, G_i+1/4, R_i+1/4, W_i in; R_i out
+        "final_gather": 9.0 * n + 3.0 * m,                         # u8 tile + G1/4 + R1/4 in; u8 canvas out
+        "psnr_sse": 6.0 * m,
+        "ssim_uniform7": 6.0 * m,
+        "ssim_gauss11": 6.0 * m,
+        "ssim_simple": 6.0 * m,
+        # the reference-shaped model of SURVEY 8(d) (scatter into fp32 accumulators), for comparison
+        "_survey_blend_model": 63.30 * n + 19.0 * m,
+    }
+
+
+def cpu_baseline(seed_img: np.ndarray, geo_full, budget_tiles=(2, 2)) -> dict:
+    """The CPU oracle on a bounded sample: a rows x cols corner of the same tile grid
+    (same tile size / overlap / levels), tile extract + Laplacian blend + PSNR + 3 x SSIM."""
+    from oracle import oracle_c as oc
+    rows, cols = budget_tiles
+    x0, y0, tw, th = geo_full.rects[0]
+    step_x = geo_full.rects[1][0] - x0 if len(geo_full.rects) > 1 else tw
+    ncols_full = sum(1 for r in geo_full.rects if r[1] == y0)
+    step_y = geo_full.rects[ncols_full][1] - y0 if len(geo_full.rects) > ncols_full else th
+    W, H = (cols - 1) * step_x + tw, (rows - 1) * step_y + th
+    scale = geo_full.canvas_w / seed_img.shape[1]
+    sw, sh = int(np.ceil(W / scale)) + 4, int(np.ceil(H / scale)) + 4
+    src = np.ascontiguousarray(seed_img[:sh, :sw])
+    t_setup = time.perf_counter()
+    ref = oc.resize_cubic_u8(src, int(sw * scale), int(sh * scale))[:H, :W]
+    img = np.ascontiguousarray(ref)
+    ref = np.ascontiguousarray(np.clip(ref.astype(np.int16) + 2, 0, 255).astype(np.uint8))
+    t_setup = time.perf_counter() - t_setup
+    rects = [(c * step_x, r * step_y, tw, th) for r in range(rows) for c in range(cols)]
+    t0 = time.perf_counter()
+    tiles = [np.ascontiguousarray(img[y:y + h, x:x + w]) for (x, y, w, h) in rects]          # tile
+    t1 = time.perf_counter()
+    canvas = oc.laplacian_fusion(tiles, [(y, x) for (x, y, _, _) in rects], (H, W), geo_full.levels,
+                                 geo_full.weight_type)                                          # blend
+    t2 = time.perf_counter()
+    oc.psnr(ref, canvas)                                                                        # QA
+    g1, g2 = oc.rgb2gray_u8(ref), oc.rgb2gray_u8(canvas)
+    for mode in ("uniform", "gauss", "simple"):
+        oc.ssim(g1, g2, mode)
+    t3 = time.perf_counter()
+    mp = W * H / 1e6
+    return {"value": mp / (t3 - t0), "unit": "MP/s", "cores": oc.num_threads(), "kind": "port",
+            "sample": f"{rows}x{cols} corner of the tile grid ({W}x{H} = {mp:.1f} MP canvas, tiles {tw}x{th}): "
+                      f"extract {t1 - t0:.2f}s + laplacian blend {t2 - t1:.2f}s + PSNR/3xSSIM {t3 - t2:.2f}s; "
+                      f"oracle/sr_oracle.c with OpenMP (restated reference CPU path, cv2/skimage absent)"}
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="200MP", choices=["4MP", "100MP", "150MP", "200MP"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="skip the per-kernel HIP-event timing")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import _native
+    import device_pipeline as dp
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
+            return 2
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible -- the HIP path has no CPU fallback", file=sys.stderr)
+        return 2
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    geo = dp.workload_geometry(args.workload)
+    H, W, cn = geo.canvas_h, geo.canvas_w, geo.cn
+
+    # ---- inputs, resident in HBM before the timed region ----------------------------------------
+    # reference = whole-image bicubic upscale of the synthetic 720p source; image (the "SR output" the
+    # tiles are cut from) = the same upscale of a slightly different noise draw, so PSNR is finite.
+    src_ref = synthetic_source()
+    src_img = np.clip(src_ref.astype(np.int16) + np.random.default_rng(7).integers(-3, 4, src_ref.shape), 0, 255).astype(np.uint8)
+    pipe = dp.DevicePipeline(geo, rank, world, local_rank)
+    ctx = pipe.ctx
+    t_src = torch.from_numpy(np.stack([src_ref, src_img])).to(dev)
+    reference = torch.empty((H, W * cn), dtype=torch.uint8, device=dev)
+    image = torch.empty((H, W * cn), dtype=torch.uint8, device=dev)
+    sh, sw = src_ref.shape[:2]
+    ctx.resize_cubic_u8(t_src[0].data_ptr(), sw * cn, sh, sw, cn, reference.data_ptr(), W * cn, H, W)
+    ctx.resize_cubic_u8(t_src[1].data_ptr(), sw * cn, sh, sw, cn, image.data_ptr(), W * cn, H, W)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        pipe.step(image, reference)
+    torch.cuda.synchronize()
+
+    if not args.no_prof:
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pipe.step(image, reference)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = {} if args.no_prof else ctx.prof_get()
+    ctx.prof_enable(False)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    metrics = pipe.metrics()
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        mp = geo.canvas_pixels / 1e6
+        alg = algorithmic_bytes(geo)
+        kernels = {}
+        for name, (ms, launches) in prof.items():
+            per_step_ms = ms / args.steps
+            b = alg.get(name)
+            share = 1.0 / world if world > 1 else 1.0     # each rank moves ~1/N of the bytes (+ halo)
+            kernels[name] = {"ms_per_step": round(per_step_ms, 4), "launches_per_step": launches / args.steps,
+                             "alg_GB": None if b is None else round(b * share / 1e9, 4),
+                             "GBps": None if b is None or per_step_ms <= 0 else round(b * share / 1e9 / (per_step_ms / 1e3), 1)}
+        roofline = None
+        cands = [(v["ms_per_step"], k) for k, v in kernels.items() if v["alg_GB"] is not None]
+        if cands:
+            _, dom = max(cands)
+            k = kernels[dom]
+            per_launch_ms = k["ms_per_step"] / max(k["launches_per_step"], 1)
+            achieved = k["alg_GB"] / k["launches_per_step"] / (per_launch_ms / 1e3) if per_launch_ms > 0 else 0.0
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "avg_launch_ms": round(per_launch_ms, 4),
+                        "alg_bytes_per_launch": k["alg_GB"] / k["launches_per_step"] * 1e9}
+        gpu_ms = sum(v["ms_per_step"] for v in kernels.values())
+        blend_ms = sum(v["ms_per_step"] for kk, v in kernels.items()
+                       if kk in ("weight_down", "down_l0", "down_l1p", "up_level", "final_gather"))
+        total_alg = sum(alg[kk] for kk in kernels if kk in alg)
+        out = {
+            "metric": "megapixels/sec tile+blend+QA at 200MP, 1/2/4/8 GPU",
+            "value": round(mp / (elapsed / args.steps), 1),
+            "unit": "MP/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"720p->{args.workload} {geo.canvas_w}x{geo.canvas_h} canvas, "
+                                   f"{len(geo.rects)} tiles {geo.rects[0][2]}x{geo.rects[0][3]}, {geo.levels}-level "
+                                   f"Laplacian blend (cosine weights) + PSNR + SSIM(uniform7,gauss11,simple)",
+                       "tile_pixels": geo.tile_pixels, "canvas_pixels": geo.canvas_pixels,
+                       "parallelism": f"strips{world}" if world > 1 else "single"},
+            "roofline": roofline,
+            "kernels": kernels,
+            "summary": {"gpu_kernel_ms_per_step": round(gpu_ms, 4), "blend_ms_per_step": round(blend_ms, 4),
+                        "alg_GB_per_step": round(total_alg / 1e9, 3),
+                        "blend_GBps_vs_survey_model": None if blend_ms <= 0 else
+                        round(alg["_survey_blend_model"] / 1e9 / (blend_ms / 1e3), 1),
+                        "whole_step_alg_GBps": None if ms_per_step <= 0 else round(total_alg / 1e9 / (ms_per_step / 1e3), 1)},
+            "quality": {k: (v if np.isfinite(v) else str(v)) for k, v in metrics.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(src_ref, geo)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    pipe.close()
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -141,6 +141,11 @@ SR_API int sr_blend_plan_create(sr_ctx *ctx, const sr_tile_rect *h_tiles, int n,
                                 int canvas_w, int levels, int weight_type, int row_begin,
                                 int row_end, sr_blend_plan **out);
 SR_API int sr_blend_plan_destroy(sr_blend_plan *plan);
+/* Host-only form of the window planner (no context, no GPU): for canvas rows [row_begin,row_end)
+ * writes n x (r0, r1) = the tile-local input rows each tile must supply (r0 >= r1: tile unused).
+ * The multi-GPU exchange plan is built from this on every rank. */
+SR_API int sr_strip_tile_rows(const sr_tile_rect *h_tiles, int n, int levels, int canvas_h,
+                              int row_begin, int row_end, int *h_rows);
 /* tile-local rows [*r0, *r1) of tile t that the plan reads (empty if r0 >= r1): what a strip
  * owner must hold / receive for that tile. */
 SR_API int sr_blend_plan_tile_rows(const sr_blend_plan *plan, int t, int *r0, int *r1);

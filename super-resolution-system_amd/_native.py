@@ -79,6 +79,7 @@ SIGNATURES = {
     "sr_pyr_up_add": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "sr_blend_plan_create": (_i, [_vp, C.POINTER(TileRect), _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
     "sr_blend_plan_destroy": (_i, [_vp]),
+    "sr_strip_tile_rows": (_i, [C.POINTER(TileRect), _i, _i, _i, _i, _i, _pi]),
     "sr_blend_plan_tile_rows": (_i, [_vp, _i, _pi, _pi]),
     "sr_blend_plan_workspace_bytes": (_i, [_vp, C.POINTER(_sz)]),
     "sr_laplacian_blend": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_i64), _vp, _i64, _vp]),
@@ -187,6 +188,15 @@ def weight_lut(fw: int, weight_type: str) -> np.ndarray:
     out = np.empty(fw + 1, dtype=np.float32)
     check(load().sr_weight_lut(fw, WEIGHT_TYPES[weight_type], out.ctypes.data_as(C.POINTER(C.c_float))))
     return out
+
+
+def strip_tile_rows(rects_xywh, levels: int, canvas_h: int, row_begin: int, row_end: int):
+    """Host-only: tile-local input rows [(r0, r1)] every tile must supply for canvas rows [row_begin,row_end)."""
+    n = len(rects_xywh)
+    rects = (TileRect * n)(*[TileRect(int(x), int(y), int(w), int(h)) for (x, y, w, h) in rects_xywh])
+    out = (C.c_int * (2 * n))()
+    check(load().sr_strip_tile_rows(rects, n, int(levels), int(canvas_h), int(row_begin), int(row_end), out))
+    return [(out[2 * i], out[2 * i + 1]) for i in range(n)]
 
 
 def psnr_from_sse(sse: int, count: int, data_range: float = 255.0) -> float:
@@ -386,6 +396,29 @@ class Context:
             check(self.lib.sr_weighted_fusion_host(self.handle, dt, ptrs, rects, n, cn, H, W,
                                                    WEIGHT_TYPES[weight_type], out.ctypes.data_as(C.c_void_p), fptr))
         return (out, outf) if return_float else out
+
+
+def _feather_merge_np(self, arrays, descs, output_width: int, output_height: int, blending: bool = True) -> np.ndarray:
+    """TilingModule.merge_tiles on the GPU: arrays are HxWx3 u8 tiles, descs dicts with the sr_merge_tile fields."""
+    n = len(arrays)
+    bufs = [self.upload(a) for a in arrays]
+    mt = (MergeTile * n)(*[MergeTile(*[int(d[k]) for k in ("x", "y", "src_w", "src_h", "out_w", "out_h",
+                                                             "ov_t", "ov_b", "ov_l", "ov_r")]) for d in descs])
+    ptrs = (C.c_void_p * n)(*[C.c_void_p(b.ptr) for b in bufs])
+    st = (C.c_int64 * n)(*[a.shape[1] * 3 for a in arrays])
+    canvas = self.alloc(output_width * output_height * 3)
+    try:
+        check(self.lib.sr_feather_merge(self.handle, mt, n, ptrs, st, 1 if blending else 0, C.c_void_p(canvas.ptr),
+                                        output_width * 3, output_height, output_width))
+        return self.download(canvas.ptr, (output_height, output_width, 3), np.uint8)
+    finally:
+        self.sync()
+        for b in bufs:
+            b.free()
+        canvas.free()
+
+
+Context.feather_merge_np = _feather_merge_np
 
 
 class BlendPlan:

@@ -1,0 +1,282 @@
+"""blending_module -- MI355X-native mirror of the reference's blending_module.py call surface.
+
+Same names, argument meaning, return types and error behaviour as the reference for the tile ->
+blend hot path (reference blending_module.py:38-56,96-136,164-363,369-561,661-760,1245-1270,
+1492-1560,1665-1705); the arithmetic runs in hand-written HIP kernels behind the C ABI
+(include/sr_hip.h) -- there is no NumPy/OpenCV compute path here and no CPU fallback: without
+libsrhip.so or a GPU the compute methods raise.
+
+Out of scope for this path: Poisson / gradient-domain fusion, seam detect/repair,
+colour correction, feather_blend's distance transform.  Those methods exist so callers get a clear
+NotImplementedError instead of an AttributeError.
+
+Reference quirks kept: bare arrays without output_shape fail like the
+reference (ValueError: max() of an empty sequence); the canvas perimeter, where every tile's cosine
+weight is 0, saturates; ``overlap_map`` is accepted and ignored (blending_module.py:372 never reads it).
+"""
+from __future__ import annotations
+
+import logging
+from concurrent.futures import ThreadPoolExecutor
+from dataclasses import dataclass, field
+from enum import Enum
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+import _native
+
+logger = logging.getLogger(__name__)
+
+
+class FusionMethod(Enum):
+    LAPLACIAN = "laplacian"
+    POISSON = "poisson"
+    WEIGHTED_AVERAGE = "weighted"
+
+
+class PoissonMode(Enum):
+    # values of cv2.NORMAL_CLONE / MIXED_CLONE / MONOCHROME_TRANSFER (blending_module.py:45-49)
+    NORMAL = 1
+    MIXED = 2
+    MONOCHROME = 3
+
+
+class WeightType(Enum):
+    LINEAR = "linear"
+    COSINE = "cosine"
+    SIGMOID = "sigmoid"
+
+
+@dataclass
+class Seam:
+    """Seam record (blending_module.py:59-93): severity is derived from the local SSIM score."""
+    x: int
+    y: int
+    width: int
+    height: int
+    ssim_score: float
+    severity: str = field(default="low")
+    suggested_fix: str = field(default="")
+
+    def __post_init__(self):
+        if self.ssim_score < 0.85:
+            self.severity, self.suggested_fix = "high", "poisson_refinement"
+        elif self.ssim_score < 0.92:
+            self.severity, self.suggested_fix = "medium", "increase_blend_width"
+        else:
+            self.severity, self.suggested_fix = "low", "none"
+
+
+@dataclass
+class TileInfo:
+    """Tile + its top-left position on the canvas (blending_module.py:96-112)."""
+    image: np.ndarray
+    x: int
+    y: int
+    row: int
+    col: int
+
+
+@dataclass
+class OverlapRegion:
+    """Pairwise overlap rectangle of two grid neighbours (blending_module.py:115-136)."""
+    tile1_idx: int
+    tile2_idx: int
+    x1_start: int
+    y1_start: int
+    x2_start: int
+    y2_start: int
+    width: int
+    height: int
+    direction: str
+
+
+def _weight_name(weight_type: Union[WeightType, str]) -> str:
+    if isinstance(weight_type, WeightType):
+        return weight_type.value
+    name = str(weight_type)
+    # the reference's else-branch treats anything unknown as linear (blending_module.py:558-559)
+    return name if name in ("linear", "cosine", "sigmoid") else "linear"
+
+
+class BlendingModule:
+    """Tile fusion on the GPU.  Holds configuration only, so one instance may be used from several
+    threads (ParallelBlender does); device work is serialised per context inside the library."""
+
+    def __init__(self, method: str = 'laplacian', num_levels: int = 6, ssim_threshold: float = 0.95,
+                 use_cuda: bool = False, device: int = 0):
+        self.method = FusionMethod(method)          # ValueError on an unknown name, as the reference
+        self.num_levels = num_levels
+        self.ssim_threshold = ssim_threshold
+        # the reference's flag selects cv2.cuda; here every path is the HIP path
+        self.use_cuda = bool(use_cuda)
+        self.device = device
+        logger.info("BlendingModule initialized: method=%s, levels=%s (HIP/gfx950 backend)", method, num_levels)
+
+    # -- device ------------------------------------------------------------------------------
+    def _ctx(self) -> "_native.Context":
+        return _native.default_context(self.device)
+
+    # -- pyramids (blending_module.py:217-363) ----------------------------------------------------
+    def build_gaussian_pyramid(self, image: np.ndarray, levels: Optional[int] = None) -> List[np.ndarray]:
+        if levels is None:
+            levels = self.num_levels
+        cur = np.asarray(image)
+        if cur.dtype != np.float32:
+            cur = cur.astype(np.float32)
+        pyramid = [cur.copy()]
+        ctx = self._ctx()
+        for i in range(levels - 1):
+            if cur.shape[0] < 2 or cur.shape[1] < 2:
+                logger.warning("Stopping pyramid at level %d: image too small", i + 1)
+                break
+            cur = ctx.pyr_down_np(cur)
+            pyramid.append(cur)
+        return pyramid
+
+    def build_laplacian_pyramid(self, gaussian_pyramid: Sequence[np.ndarray]) -> List[np.ndarray]:
+        ctx = self._ctx()
+        out = []
+        for i in range(len(gaussian_pyramid) - 1):
+            cur, nxt = gaussian_pyramid[i], gaussian_pyramid[i + 1]
+            out.append(ctx.pyr_up_np(nxt, cur.shape[:2], cur, "sub"))
+        out.append(gaussian_pyramid[-1])
+        return out
+
+    def collapse_laplacian_pyramid(self, laplacian_pyramid: Sequence[np.ndarray]) -> np.ndarray:
+        ctx = self._ctx()
+        cur = np.array(laplacian_pyramid[-1], dtype=np.float32, copy=True)
+        for i in range(len(laplacian_pyramid) - 2, -1, -1):
+            layer = laplacian_pyramid[i]
+            cur = ctx.pyr_up_np(cur, layer.shape[:2], layer, "add")
+        return cur
+
+    # -- tile list handling shared by the fusions ---------------------------------------------------
+    @staticmethod
+    def _collect(tiles, output_shape, guess_without_shape: bool):
+        images, positions = [], []
+        for i, tile in enumerate(tiles):
+            if isinstance(tile, TileInfo):
+                images.append(np.asarray(tile.image))
+                positions.append((int(tile.y), int(tile.x)))
+            else:
+                arr = np.asarray(tile)
+                images.append(arr)
+                if output_shape or guess_without_shape:
+                    grid = int(np.ceil(np.sqrt(len(tiles))))
+                    th, tw = arr.shape[:2]
+                    positions.append(((i // grid) * th, (i % grid) * tw))
+        if output_shape is None:
+            # bare arrays in laplacian_fusion leave `positions` empty -> max() of an empty sequence
+            output_shape = (max(p[0] + im.shape[0] for im, p in zip(images, positions)),
+                            max(p[1] + im.shape[1] for im, p in zip(images, positions)))
+        if len(positions) != len(images):
+            raise ValueError("tiles mix TileInfo and bare arrays without an output_shape")
+        return images, positions, (int(output_shape[0]), int(output_shape[1]))
+
+    def _fuse(self, images, positions, output_shape, weight_name: str, laplacian: bool) -> np.ndarray:
+        ndims = {im.ndim for im in images}
+        if ndims - {2, 3} or len(ndims) != 1:
+            raise ValueError("tiles must all be HxW or all HxWxC arrays")
+        return self._ctx().fusion_np(images, positions, output_shape, self.num_levels, weight_name,
+                                     laplacian=laplacian)
+
+    # -- fusions ----------------------------------------------------------------------------------
+    def laplacian_fusion(self, tiles: List[Union[np.ndarray, TileInfo]],
+                         overlap_map: Optional[List[OverlapRegion]] = None,
+                         output_shape: Optional[Tuple[int, int]] = None,
+                         weight_type: WeightType = WeightType.COSINE) -> np.ndarray:
+        """Laplacian-pyramid fusion (blending_module.py:369-506) -> uint8 canvas."""
+        del overlap_map
+        images, positions, shape = self._collect(tiles, output_shape, guess_without_shape=False)
+        return self._fuse(images, positions, shape, _weight_name(weight_type), laplacian=True)
+
+    def weighted_average_fusion(self, tiles: List[Union[np.ndarray, TileInfo]],
+                                weights: Optional[List[np.ndarray]] = None,
+                                weight_type: WeightType = WeightType.COSINE,
+                                output_shape: Optional[Tuple[int, int]] = None) -> np.ndarray:
+        """Distance-weighted average (blending_module.py:661-760)."""
+        if weights is not None and len(weights) > 0:
+            raise NotImplementedError("caller-supplied weight maps are not wired to the HIP path yet")
+        images, positions, shape = self._collect(tiles, output_shape, guess_without_shape=True)
+        return self._fuse(images, positions, shape, _weight_name(weight_type), laplacian=False)
+
+    def multi_band_fusion(self, tiles, num_bands: int = 6, output_shape: Optional[Tuple[int, int]] = None) -> np.ndarray:
+        """blending_module.py:1245-1270: laplacian_fusion with sigmoid weights (num_bands is unused there too)."""
+        return self.laplacian_fusion(tiles, output_shape=output_shape, weight_type=WeightType.SIGMOID)
+
+    def _create_distance_weight_map(self, height: int, width: int, weight_type: WeightType,
+                                    feather_width: Optional[int] = None) -> np.ndarray:
+        """blending_module.py:508-561.  The map depends on the integer edge distance only, so it is the
+        C ABI's LUT (sr_weight_lut) indexed by min(d, feather_width)."""
+        if feather_width is None:
+            feather_width = min(height, width) // 8
+        lut = _native.weight_lut(int(feather_width), _weight_name(weight_type))
+        y = np.arange(height).reshape(-1, 1)
+        x = np.arange(width).reshape(1, -1)
+        d = np.minimum(np.minimum(y, height - 1 - y), np.minimum(x, width - 1 - x))
+        return lut[np.minimum(d, feather_width)]
+
+    # -- not on this path ---------------------------------------------------------------------------
+    def _out_of_scope(self, name: str):
+        raise NotImplementedError(f"BlendingModule.{name} is outside the MI355X tile->blend->assess path "
+                                  f"(SURVEY.md 2c); use the reference implementation for it")
+
+    def poisson_fusion(self, *a, **k):
+        self._out_of_scope("poisson_fusion")
+
+    def feather_blend(self, *a, **k):
+        self._out_of_scope("feather_blend")
+
+    def gradient_domain_fusion(self, *a, **k):
+        self._out_of_scope("gradient_domain_fusion")
+
+    def detect_seams(self, *a, **k):
+        self._out_of_scope("detect_seams")
+
+    def repair_seams(self, *a, **k):
+        self._out_of_scope("repair_seams")
+
+    def color_correction(self, *a, **k):
+        self._out_of_scope("color_correction")
+
+
+def create_tile_grid(images: List[np.ndarray], grid_shape: Tuple[int, int],
+                     overlap: int = 100) -> Tuple[List[TileInfo], List[OverlapRegion]]:
+    """Grid -> positions x = col*(tw-ov), y = row*(th-ov) and the 4-neighbour overlap rectangles
+    (blending_module.py:1492-1560).  Pure integer bookkeeping."""
+    rows, cols = grid_shape
+    th, tw = images[0].shape[:2]
+    infos = [TileInfo(img, (i % cols) * (tw - overlap), (i // cols) * (th - overlap), i // cols, i % cols)
+             for i, img in enumerate(images)]
+    regions = []
+    for i, a in enumerate(infos):
+        for j in range(i + 1, len(infos)):
+            b = infos[j]
+            if abs(a.row - b.row) + abs(a.col - b.col) != 1:
+                continue
+            x_min, y_min = max(a.x, b.x), max(a.y, b.y)
+            x_max = min(a.x + a.image.shape[1], b.x + b.image.shape[1])
+            y_max = min(a.y + a.image.shape[0], b.y + b.image.shape[0])
+            if x_max > x_min and y_max > y_min:
+                regions.append(OverlapRegion(i, j, x_min - a.x, y_min - a.y, x_min - b.x, y_min - b.y,
+                                             x_max - x_min, y_max - y_min,
+                                             'horizontal' if a.row == b.row else 'vertical'))
+    return infos, regions
+
+
+class ParallelBlender:
+    """Thread-pool fan-out of laplacian_fusion over tile groups (blending_module.py:1665-1705)."""
+
+    def __init__(self, num_workers: int = 4):
+        self.num_workers = num_workers
+        self.executor = ThreadPoolExecutor(max_workers=num_workers)
+
+    def blend_tiles_parallel(self, blender: BlendingModule, tile_groups: List[List[TileInfo]],
+                             output_shape: Tuple[int, int]) -> List[np.ndarray]:
+        futures = [self.executor.submit(blender.laplacian_fusion, tiles, None, output_shape) for tiles in tile_groups]
+        return [f.result() for f in futures]
+
+    def close(self):
+        self.executor.shutdown()

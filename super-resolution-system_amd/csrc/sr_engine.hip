@@ -704,6 +704,103 @@ static void cubic_table(int n_src, int n_dst, std::vector<CubicTab> &tab)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// TilingModule.merge_tiles feather path (tiling_module.py:1074-1175), canvas-centric
+// ---------------------------------------------------------------------------------------------
+struct LinTab {
+    int ofs;       // left / top source index (clamped)
+    short a0, a1;  // 11-bit coefficients of cv::resize INTER_LINEAR
+};
+
+struct MergeDev {
+    int x, y, src_w, src_h, out_w, out_h;
+    int ov_t, ov_b, ov_l, ov_r;
+    int resize;          // 1: bilinear resize src -> out
+    int xtab, ytab;      // offsets into the LinTab array
+    double st, sb, sl, sr;  // np.linspace steps: +1/(ov-1) (top/left), -1/(ov-1) (bottom/right); 0 when ov == 1
+};
+
+__global__ __launch_bounds__(256) void k_feather_merge(const MergeDev *__restrict__ tiles, const TileSrc *__restrict__ srcs,
+                                                       const LinTab *__restrict__ tabs, int n, int blending,
+                                                       unsigned char *__restrict__ canvas, long long cstride, int ch,
+                                                       int cw)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= cw || y >= ch) return;
+    float acc[3] = {0.f, 0.f, 0.f};
+    float wacc = 0.f;
+    for (int t = 0; t < n; ++t) {
+        const MergeDev &T = tiles[t];
+        const int lx = x - T.x, ly = y - T.y;
+        if (lx < 0 || ly < 0 || lx >= T.out_w || ly >= T.out_h) continue;
+        float w = 1.0f;
+        if (blending) {
+            // weight[:t] *= linspace(0,1,t); weight[-b:] *= linspace(1,0,b); then columns -- each product in
+            // float64, rounded to fp32 (NumPy's in-place multiply of an fp32 array by an fp64 ramp)
+            if (T.ov_t > 0 && ly < T.ov_t) {
+                const double r = (ly == T.ov_t - 1 && T.ov_t > 1) ? 1.0 : (double)ly * T.st + 0.0;
+                w = (float)((double)w * r);
+            }
+            if (T.ov_b > 0 && ly >= T.out_h - T.ov_b) {
+                const int i = ly - (T.out_h - T.ov_b);
+                const double r = (i == T.ov_b - 1 && T.ov_b > 1) ? 0.0 : (double)i * T.sb + 1.0;
+                w = (float)((double)w * r);
+            }
+            if (T.ov_l > 0 && lx < T.ov_l) {
+                const double r = (lx == T.ov_l - 1 && T.ov_l > 1) ? 1.0 : (double)lx * T.sl + 0.0;
+                w = (float)((double)w * r);
+            }
+            if (T.ov_r > 0 && lx >= T.out_w - T.ov_r) {
+                const int i = lx - (T.out_w - T.ov_r);
+                const double r = (i == T.ov_r - 1 && T.ov_r > 1) ? 0.0 : (double)i * T.sr + 1.0;
+                w = (float)((double)w * r);
+            }
+        }
+        const unsigned char *base = (const unsigned char *)srcs[t].p;
+        const long long st = srcs[t].stride;
+        if (T.resize) {
+            const LinTab X = tabs[T.xtab + lx], Y = tabs[T.ytab + ly];
+            const int x1 = min(X.ofs + 1, T.src_w - 1), y1 = min(Y.ofs + 1, T.src_h - 1);
+            const unsigned char *r0 = base + (size_t)Y.ofs * st, *r1 = base + (size_t)y1 * st;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int s0 = (int)r0[X.ofs * 3 + c] * X.a0 + (int)r0[x1 * 3 + c] * X.a1;
+                const int s1 = (int)r1[X.ofs * 3 + c] * X.a0 + (int)r1[x1 * 3 + c] * X.a1;
+                const int v = (((Y.a0 * (s0 >> 4)) >> 16) + ((Y.a1 * (s1 >> 4)) >> 16) + 2) >> 2;
+                acc[c] += (float)(unsigned char)v * w;
+            }
+        } else {
+            const unsigned char *r0 = base + (size_t)ly * st + (size_t)lx * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[c] += (float)r0[c] * w;
+        }
+        wacc += w;
+    }
+    const float wv = wacc > 1e-6f ? wacc : 1e-6f;
+    unsigned char *o = canvas + (size_t)y * cstride + (size_t)x * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = (unsigned char)(int)(acc[c] / wv);   // astype(uint8): truncation, no clip
+}
+
+static void linear_table(int n_src, int n_dst, std::vector<LinTab> &tab)
+{
+    const size_t base = tab.size();
+    tab.resize(base + n_dst);
+    const double scale = 1.0 / ((double)n_dst / (double)n_src);
+    for (int d = 0; d < n_dst; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)floorf(f);
+        f -= (float)s;
+        if (s < 0) { f = 0.f; s = 0; }
+        if (s >= n_src - 1) { f = 0.f; s = n_src - 1; }
+        LinTab &t = tab[base + d];
+        t.ofs = s;
+        t.a0 = (short)rintf((1.0f - f) * 2048.0f);
+        t.a1 = (short)rintf(f * 2048.0f);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // blend plan (host object)
 // ---------------------------------------------------------------------------------------------
@@ -1368,11 +1465,60 @@ int sr_weighted_fusion_host(sr_ctx *ctx, int dtype, const void *const *h_tiles, 
                             h_canvas_f32);
 }
 
-int sr_feather_merge(sr_ctx *ctx, const sr_merge_tile *, int, void *const *, const int64_t *, int, uint8_t *, int64_t,
-                     int, int)
+int sr_feather_merge(sr_ctx *ctx, const sr_merge_tile *h_tiles, int n, void *const *h_d_tiles,
+                     const int64_t *h_strides, int blending, uint8_t *d_canvas, int64_t canvas_stride, int canvas_h,
+                     int canvas_w)
 {
     CTX_ENTER(ctx);
-    return sr_set_error(SR_ERR_UNSUPPORTED, "sr_feather_merge: not built yet");
+    if (!h_tiles || !h_d_tiles || !h_strides || !d_canvas || n < 0 || canvas_h < 1 || canvas_w < 1)
+        return sr_set_error(SR_ERR_INVALID_ARG, "sr_feather_merge: bad arguments");
+    if (canvas_stride < (int64_t)canvas_w * 3) return sr_set_error(SR_ERR_SHAPE, "sr_feather_merge: canvas stride too small");
+    std::vector<MergeDev> md(n);
+    std::vector<TileSrc> srcs(n);
+    std::vector<LinTab> tabs;
+    for (int t = 0; t < n; ++t) {
+        const sr_merge_tile &m = h_tiles[t];
+        if (m.src_w < 1 || m.src_h < 1 || m.out_w < 1 || m.out_h < 1 || m.x < 0 || m.y < 0 || !h_d_tiles[t])
+            return sr_set_error(SR_ERR_INVALID_ARG, "sr_feather_merge: tile %d has a bad descriptor", t);
+        if (blending && (m.ov_t > m.out_h || m.ov_b > m.out_h || m.ov_l > m.out_w || m.ov_r > m.out_w))
+            return sr_set_error(SR_ERR_SHAPE,
+                                "sr_feather_merge: tile %d: overlap ramp longer than the tile (NumPy cannot broadcast "
+                                "the reference's ramp either)", t);
+        MergeDev &D = md[t];
+        D.x = m.x; D.y = m.y; D.src_w = m.src_w; D.src_h = m.src_h; D.out_w = m.out_w; D.out_h = m.out_h;
+        D.ov_t = std::max(m.ov_t, 0); D.ov_b = std::max(m.ov_b, 0); D.ov_l = std::max(m.ov_l, 0); D.ov_r = std::max(m.ov_r, 0);
+        D.resize = (m.src_w != m.out_w || m.src_h != m.out_h) ? 1 : 0;
+        D.xtab = D.ytab = 0;
+        if (D.resize) {
+            D.xtab = (int)tabs.size();
+            linear_table(m.src_w, m.out_w, tabs);
+            D.ytab = (int)tabs.size();
+            linear_table(m.src_h, m.out_h, tabs);
+        }
+        auto step = [](int ov, double delta) { return ov > 1 ? delta / (double)(ov - 1) : 0.0; };
+        D.st = step(D.ov_t, 1.0); D.sb = step(D.ov_b, -1.0); D.sl = step(D.ov_l, 1.0); D.sr = step(D.ov_r, -1.0);
+        srcs[t].p = h_d_tiles[t];
+        srcs[t].stride = h_strides[t];
+        if (h_strides[t] < (int64_t)m.src_w * 3) return sr_set_error(SR_ERR_SHAPE, "sr_feather_merge: tile %d stride too small", t);
+    }
+    const size_t b0 = sizeof(MergeDev) * (size_t)n, b1 = sizeof(TileSrc) * (size_t)n, b2 = sizeof(LinTab) * tabs.size();
+    auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+    void *scr = nullptr;
+    int rc = ctx_scratch(ctx, al(b0) + al(b1) + al(b2) + 256, &scr);
+    if (rc) return rc;
+    char *p0 = (char *)scr, *p1 = p0 + al(b0), *p2 = p1 + al(b1);
+    if (n > 0) {
+        HIPCHK(upload_small(ctx, p0, md.data(), b0));
+        HIPCHK(upload_small(ctx, p1, srcs.data(), b1));
+        if (b2) HIPCHK(upload_small(ctx, p2, tabs.data(), b2));
+    }
+    {
+        ProfScope ps(ctx, "feather_merge");
+        dim3 grid((canvas_w + 63) / 64, (canvas_h + 3) / 4), block(64, 4);
+        hipLaunchKernelGGL(k_feather_merge, grid, block, 0, ctx->stream, (const MergeDev *)p0, (const TileSrc *)p1,
+                           (const LinTab *)p2, n, blending ? 1 : 0, d_canvas, (long long)canvas_stride, canvas_h, canvas_w);
+    }
+    return check_launch("feather_merge");
 }
 
 // ---- metrics ------------------------------------------------------------------------------------------

@@ -129,6 +129,25 @@ int sr_weight_lut(int fw, int weight_type, float *h_lut)
     return SR_OK;
 }
 
+int sr_strip_tile_rows(const sr_tile_rect *h_tiles, int n, int levels, int canvas_h, int row_begin, int row_end,
+                       int *h_rows)
+{
+    if (!h_tiles || !h_rows || n < 0 || levels < 1 || canvas_h < 1)
+        return sr_set_error(SR_ERR_INVALID_ARG, "sr_strip_tile_rows: bad arguments");
+    row_begin = std::max(row_begin, 0);
+    row_end = std::min(row_end, canvas_h);
+    for (int t = 0; t < n; ++t) {
+        const sr_tile_rect &r = h_tiles[t];
+        if (r.w < 1 || r.h < 1 || r.x < 0 || r.y < 0)
+            return sr_set_error(SR_ERR_INVALID_ARG, "sr_strip_tile_rows: tile %d has a bad rectangle", t);
+        SrTileLevels lv;
+        sr_plan_windows(r.h, r.w, r.y, std::min(levels, SR_MAX_LEVELS), row_begin, row_end, canvas_h, &lv);
+        h_rows[2 * t] = lv.gw[0].a;
+        h_rows[2 * t + 1] = lv.gw[0].b;
+    }
+    return SR_OK;
+}
+
 double sr_psnr_from_sse(uint64_t sse, uint64_t count, double data_range)
 {
     if (count == 0) return NAN;

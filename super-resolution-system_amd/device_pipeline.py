@@ -1,0 +1,263 @@
+"""Device-resident tile -> blend -> assess pipeline, one process per GPU.
+
+This is the data-parallel form of the reference's stages 1/3/4 (main.py:293-379): tiles live in HBM
+on the GPU that owns them, the canvas is partitioned into horizontal strips (one per rank), every
+strip owner receives the tile rows (plus pyramid halo) it needs over RCCL / xGMI and blends its rows
+with exactly the kernels of the single-GPU path, so its rows are bit-identical to a 1-GPU run
+(SURVEY.md 8(e)).  Quality metrics are partial sums per strip + one 5-element all-reduce.
+
+torch is used for what it is good at here: device buffers, the current stream and
+torch.distributed (backend "nccl" == RCCL on ROCm; "gloo" for the CPU rehearsal in tests/).
+All arithmetic goes through the C ABI (``_native``).
+"""
+from __future__ import annotations
+
+import bisect
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+import _native
+
+SSIM_HALO = 5   # rows of canvas a strip needs beyond its own for the 11-tap SSIM windows
+
+
+@dataclass
+class Geometry:
+    """Output-space tile arrangement (rects are (x, y, w, h) like blending_module.TileInfo)."""
+    canvas_w: int
+    canvas_h: int
+    rects: List[Tuple[int, int, int, int]]
+    cn: int = 3
+    levels: int = 6
+    weight_type: str = "cosine"
+
+    @property
+    def tile_pixels(self) -> int:
+        return sum(w * h for (_, _, w, h) in self.rects)
+
+    @property
+    def canvas_pixels(self) -> int:
+        return self.canvas_w * self.canvas_h
+
+
+def grid_geometry(tile_w: int, tile_h: int, rows: int, cols: int, ov_x: int, ov_y: Optional[int] = None,
+                  levels: int = 6, weight_type: str = "cosine") -> Geometry:
+    """blending_module.create_tile_grid rule: x = col*(tw-ov), y = row*(th-ov) (blending_module.py:1518-1520)."""
+    ov_y = ov_x if ov_y is None else ov_y
+    rects = [((i % cols) * (tile_w - ov_x), (i // cols) * (tile_h - ov_y), tile_w, tile_h)
+             for i in range(rows * cols)]
+    return Geometry(cols * tile_w - (cols - 1) * ov_x, rows * tile_h - (rows - 1) * ov_y, rects, 3, levels,
+                    weight_type)
+
+
+# SURVEY.md 8(d) geometries (BASELINE.json configs)
+WORKLOADS = {
+    "4MP": dict(tile_w=1366, tile_h=911, rows=2, cols=2, ov_x=273, ov_y=182),
+    "100MP": dict(tile_w=4710, tile_h=3349, rows=3, cols=3, ov_x=942),
+    "150MP": dict(tile_w=4412, tile_h=3162, rows=4, cols=4, ov_x=882),
+    "200MP": dict(tile_w=4124, tile_h=2970, rows=5, cols=5, ov_x=825),
+}
+
+
+def workload_geometry(name: str) -> Geometry:
+    return grid_geometry(**WORKLOADS[name])
+
+
+# ---------------------------------------------------------------------------------------------
+# strip partition + exchange plan (host only; runs identically on every rank)
+# ---------------------------------------------------------------------------------------------
+def strip_bounds(canvas_h: int, world: int) -> List[int]:
+    return [canvas_h * r // world for r in range(world + 1)]
+
+
+def tile_owners(rects: Sequence[Tuple[int, int, int, int]], bounds: Sequence[int]) -> List[int]:
+    """Locality-aware ownership: the rank whose strip holds the tile's centre row (most of what a
+    strip needs is then already local; only rows across strip borders travel)."""
+    world = len(bounds) - 1
+    out = []
+    for (_, y, _, h) in rects:
+        c = min(y + h // 2, bounds[-1] - 1)
+        out.append(min(max(bisect.bisect_right(bounds, c) - 1, 0), world - 1))
+    return out
+
+
+@dataclass
+class ExchangePlan:
+    world: int
+    bounds: List[int]
+    owners: List[int]
+    rows: List[Tuple[int, int]]            # canvas rows [begin, end) each rank blends (strip + SSIM halo)
+    need: List[List[Tuple[int, int]]]      # need[r][t] = tile-local rows rank r reads of tile t
+
+    def sends(self, rank: int) -> List[Tuple[int, int, int, int]]:
+        """(peer, tile, r0, r1) this rank sends, in global (peer-major, tile) order."""
+        out = []
+        for r in range(self.world):
+            if r == rank:
+                continue
+            for t, (a, b) in enumerate(self.need[r]):
+                if a < b and self.owners[t] == rank:
+                    out.append((r, t, a, b))
+        return out
+
+    def recvs(self, rank: int) -> List[Tuple[int, int, int, int]]:
+        out = []
+        for t, (a, b) in enumerate(self.need[rank]):
+            if a < b and self.owners[t] != rank:
+                out.append((self.owners[t], t, a, b))
+        return sorted(out)
+
+    def bytes_received(self, rank: int, geo: Geometry) -> int:
+        return sum((b - a) * geo.rects[t][2] * geo.cn for (_, t, a, b) in self.recvs(rank))
+
+
+def make_exchange_plan(geo: Geometry, world: int, halo: int = SSIM_HALO) -> ExchangePlan:
+    bounds = strip_bounds(geo.canvas_h, world)
+    owners = tile_owners(geo.rects, bounds)
+    rows, need = [], []
+    for r in range(world):
+        a = max(bounds[r] - (halo if world > 1 else 0), 0)
+        b = min(bounds[r + 1] + (halo if world > 1 else 0), geo.canvas_h)
+        rows.append((a, b))
+        need.append(_native.strip_tile_rows(geo.rects, geo.levels, geo.canvas_h, a, b))
+    return ExchangePlan(world, bounds, owners, rows, need)
+
+
+def exchange_tile_rows(plan: ExchangePlan, rank: int, local_tiles: Dict[int, "object"],
+                       recv_bufs: Dict[int, "object"], group=None):
+    """Send the rows other strips need of the tiles this rank owns, receive the rows this strip
+    needs of tiles owned elsewhere.  Tiles are 2-D uint8 tensors [h, w*cn]; recv_bufs[t] has exactly
+    (r1 - r0) rows.  One grouped batch of point-to-point ops (ncclSend/ncclRecv under
+    ncclGroupStart/End on RCCL; plain isend/irecv on gloo).  Returns the work handles."""
+    import torch.distributed as dist
+    ops = []
+    for (peer, t, a, b) in plan.sends(rank):
+        ops.append(dist.P2POp(dist.isend, local_tiles[t][a:b], peer, group))
+    for (peer, t, a, b) in plan.recvs(rank):
+        ops.append(dist.P2POp(dist.irecv, recv_bufs[t], peer, group))
+    if not ops:
+        return []
+    return dist.batch_isend_irecv(ops)
+
+
+# ---------------------------------------------------------------------------------------------
+# per-rank device pipeline
+# ---------------------------------------------------------------------------------------------
+class DevicePipeline:
+    """tile (overlap extract) -> [exchange] -> Laplacian blend of this rank's strip -> PSNR/SSIM partials.
+
+    Inputs (resident before the timed region): ``image`` = the output-space image the tiles are cut
+    from (the SR result; the benchmark's stub is a bicubic upscale), ``reference`` = the image the
+    canvas is assessed against; both uint8 [H, W*3] torch tensors on this rank's GPU.
+    """
+
+    RESULT_FIELDS = ("sse", "ssim_uniform_sum", "ssim_gauss_sum", "ssim_simple_sum")
+
+    def __init__(self, geo: Geometry, rank: int = 0, world: int = 1, device: Optional[int] = None,
+                 group=None, ssim_modes: Sequence[str] = ("uniform", "gauss", "simple")):
+        import torch
+        self.torch = torch
+        self.geo, self.rank, self.world, self.group = geo, rank, world, group
+        self.device = torch.cuda.current_device() if device is None else device
+        self.dev = torch.device("cuda", self.device)
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        self.ctx = _native.Context(self.device, stream=stream)
+        self.ssim_modes = tuple(ssim_modes)
+        self.xplan = make_exchange_plan(geo, world)
+        self.row_begin, self.row_end = self.xplan.rows[rank]
+        self.strip = (self.xplan.bounds[rank], self.xplan.bounds[rank + 1])
+        cn = geo.cn
+        u8 = dict(dtype=torch.uint8, device=self.dev)
+        # tiles this rank owns (dense) and the row windows it receives of the others
+        self.owned = [t for t, o in enumerate(self.xplan.owners) if o == rank]
+        self.local_tiles = {t: torch.empty((geo.rects[t][3], geo.rects[t][2] * cn), **u8) for t in self.owned}
+        self.recv_bufs = {t: torch.empty((b - a, geo.rects[t][2] * cn), **u8)
+                          for (_, t, a, b) in self.xplan.recvs(rank)}
+        self.canvas = torch.zeros((geo.canvas_h, geo.canvas_w * cn), **u8)
+        self.results = torch.zeros(5, dtype=torch.float64, device=self.dev)
+        self._sse_word = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self.plan = _native.BlendPlan(self.ctx, geo.rects, cn, geo.canvas_h, geo.canvas_w, geo.levels,
+                                      geo.weight_type, self.row_begin, self.row_end)
+        # per-tile (virtual) base pointers and strides for the blend
+        self._ptrs, self._strides = [], []
+        for t, (x, y, w, h) in enumerate(geo.rects):
+            stride = w * cn
+            a, b = self.xplan.need[rank][t]
+            if a >= b:
+                self._ptrs.append(0)
+            elif t in self.local_tiles:
+                self._ptrs.append(self.local_tiles[t].data_ptr())
+            else:
+                self._ptrs.append(self.recv_bufs[t].data_ptr() - a * stride)   # virtual row 0
+            self._strides.append(stride)
+        self._ssim_counts = {}
+
+    # -- stages ---------------------------------------------------------------------------------
+    def stage_tile(self, image):
+        """Overlap-tile extract of the tiles this rank owns (tiling_module.py:713-715 slice)."""
+        if not self.owned:
+            return
+        g = self.geo
+        self.ctx.tile_extract(image.data_ptr(), g.canvas_h, g.canvas_w, g.cn, image.stride(0),
+                              [g.rects[t] for t in self.owned],
+                              [self.local_tiles[t].data_ptr() for t in self.owned],
+                              [self.local_tiles[t].stride(0) for t in self.owned])
+
+    def stage_exchange(self):
+        if self.world == 1:
+            return
+        for w in exchange_tile_rows(self.xplan, self.rank, self.local_tiles, self.recv_bufs, self.group):
+            w.wait()
+
+    def stage_blend(self):
+        self.plan.blend(self._ptrs, self._strides, self.canvas.data_ptr(), self.canvas.stride(0))
+
+    def stage_assess(self, reference):
+        """PSNR (exact integer SSE) and the SSIM modes over this rank's strip, left on the device."""
+        g = self.geo
+        s0, s1 = self.strip
+        rowlen = g.canvas_w * g.cn
+        res = self.results
+        off = s0 * rowlen
+        self.ctx.sse_u8_async(reference.data_ptr() + s0 * reference.stride(0), reference.stride(0),
+                              self.canvas.data_ptr() + off, self.canvas.stride(0), s1 - s0, rowlen,
+                              self._sse_word.data_ptr())
+        res[0] = self._sse_word[0].to(self.torch.float64)
+        for i, mode in enumerate(("uniform", "gauss", "simple")):
+            if mode not in self.ssim_modes:
+                continue
+            n = self.ctx.ssim_u8_async(reference.data_ptr(), reference.stride(0), self.canvas.data_ptr(),
+                                       self.canvas.stride(0), g.canvas_h, g.canvas_w, g.cn, mode,
+                                       res.data_ptr() + 8 * (1 + i), row_begin=s0, row_end=s1)
+            self._ssim_counts[mode] = n
+
+    def stage_reduce(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.results, op=dist.ReduceOp.SUM, group=self.group)
+
+    def step(self, image, reference):
+        self.stage_tile(image)
+        self.stage_exchange()
+        self.stage_blend()
+        self.stage_assess(reference)
+        self.stage_reduce()
+
+    # -- results ----------------------------------------------------------------------------------
+    def metrics(self) -> Dict[str, float]:
+        """Whole-image scores from the (all-reduced) partial sums; synchronises."""
+        g = self.geo
+        vals = self.results.cpu().numpy()
+        out = {"psnr": _native.psnr_from_sse(int(round(vals[0])), g.canvas_h * g.canvas_w * g.cn, 255.0)}
+        pads = {"uniform": 3, "gauss": 5, "simple": 0}
+        for i, mode in enumerate(("uniform", "gauss", "simple")):
+            if mode in self.ssim_modes:
+                cnt = (g.canvas_h - 2 * pads[mode]) * (g.canvas_w - 2 * pads[mode])
+                out[f"ssim_{mode}"] = float(vals[1 + i] / cnt)
+        return out
+
+    def close(self):
+        self.plan.close()
+        self.ctx.close()

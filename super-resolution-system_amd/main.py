@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""main -- SuperResolutionPipeline / PipelineConfig entry points over the MI355X-native stages.
+
+Keeps the reference's names, config fields and defaults, result record and five-stage order
+(main.py:47-89,92-134,157-192,269-441).  Stages 1, 3 and 4 (tile -> blend -> assess) run on the GPU
+through tiling_module / blending_module / quality_assessment_module.  Stage 2 of the reference is a
+remote vendor API (out of scope): here it is a pluggable ``sr_backend`` whose default
+is the bicubic stub of BASELINE.json's configs, executed on the GPU with the resize kernel.
+
+What is wired differently from the reference, because the reference's own wiring cannot run
+(SURVEY.md 0.3): tiles are read from ``tile.data``; ``TileInfo(image, x, y, row, col)`` is built with
+positional fields; the fused ndarray is saved through Pillow; QA receives ndarrays.  The fixed x2 tile
+scale of main.py:217,322 is kept as the default ``sr_scale`` (an added field; every original field
+keeps its name and default).  Importing this module does not create ``super_resolution.log``.
+"""
+from __future__ import annotations
+
+import asyncio
+import json
+import logging
+import sys
+import time
+from dataclasses import dataclass
+from datetime import datetime
+from pathlib import Path
+from typing import Any, Callable, Dict, List, Optional
+
+import numpy as np
+
+from blending_module import BlendingModule, TileInfo
+from quality_assessment_module import QualityAssessmentModule
+from tiling_module import Tile, TileMetadata, TilingModule
+
+logger = logging.getLogger(__name__)
+
+
+@dataclass
+class PipelineConfig:
+    """main.py:47-75 (same fields and defaults) + sr_scale."""
+    block_size: int = 2048
+    overlap_ratio: float = 0.2
+    padding_mode: str = 'mirror'
+    target_resolution: str = "100MP"
+    seedream_strength: float = 0.5
+    seedream_steps: int = 50
+    blend_method: str = 'laplacian'
+    num_pyramid_levels: int = 6
+    max_agents: int = 60
+    max_concurrent: int = 30
+    enable_qa: bool = True
+    qa_device: str = 'cpu'
+    volc_ak: str = ""
+    volc_sk: str = ""
+    volc_region: str = "cn-beijing"
+    sr_scale: int = 2          # the reference hard-codes 2 (main.py:217,322)
+
+
+@dataclass
+class PipelineResult:
+    """main.py:78-89."""
+    success: bool
+    output_path: Optional[str]
+    processing_time: float
+    total_blocks: int
+    successful_blocks: int
+    failed_blocks: int
+    quality_score: Optional[float]
+    quality_report: Optional[Dict[str, Any]]
+    error_message: Optional[str]
+
+
+def bicubic_stub_backend(pipeline: "SuperResolutionPipeline", tile: Tile, prompt: str) -> Optional[np.ndarray]:
+    """SR stand-in: cv2.INTER_CUBIC-style upscale of the padded tile by sr_scale, on the GPU."""
+    s = pipeline.config.sr_scale
+    data = tile.data
+    return pipeline.quality_module.upsample_bicubic(data, (data.shape[0] * s, data.shape[1] * s))
+
+
+class SuperResolutionPipeline:
+    """tiling -> super-resolution -> blending -> quality assessment -> output."""
+
+    def __init__(self, config: PipelineConfig, sr_backend: Optional[Callable] = None):
+        self.config = config
+        self.logger = logging.getLogger(self.__class__.__name__)
+        self.tiling_module = TilingModule(block_size=config.block_size, overlap_ratio=config.overlap_ratio,
+                                          padding_mode=config.padding_mode, output_scale=float(config.sr_scale))
+        self.blending_module = BlendingModule(method=config.blend_method, num_levels=config.num_pyramid_levels)
+        self.quality_module = QualityAssessmentModule(device=config.qa_device)
+        self.sr_backend = sr_backend or bicubic_stub_backend
+        self.sr_module = None
+        self.scheduler = None
+
+    async def __aenter__(self):
+        return self
+
+    async def __aexit__(self, exc_type, exc_val, exc_tb):
+        return None
+
+    def _calculate_target_size(self, original_size: tuple, target_resolution: str) -> tuple:
+        """main.py:157-192 (the reference defines it but process() never applies it; kept for callers)."""
+        width, height = original_size
+        presets = {"100MP": 100, "150MP": 150, "200MP": 200}
+        if target_resolution in presets:
+            import _native
+            return _native.target_size(int(width), int(height), presets[target_resolution])
+        try:
+            w, h = map(int, target_resolution.split('x'))
+            return (w, h)
+        except Exception:  # noqa: BLE001
+            self.logger.warning("无法解析目标分辨率: %s，使用默认100MP", target_resolution)
+            return (12245, 8163)
+
+    async def _process_single_tile(self, tile: Tile, prompt: str) -> Optional[np.ndarray]:
+        try:
+            return self.sr_backend(self, tile, prompt)
+        except Exception as exc:  # noqa: BLE001 - a failed tile is dropped from the blend (main.py:221-223,310-325)
+            self.logger.error("分块 %s 处理失败: %s", tile.metadata.block_id, exc)
+            return None
+
+    async def _parallel_upscale(self, tiles: List[Tile], prompt: str) -> List[Optional[np.ndarray]]:
+        sem = asyncio.Semaphore(self.config.max_concurrent)
+
+        async def limited(t: Tile):
+            async with sem:
+                return await self._process_single_tile(t, prompt)
+
+        return list(await asyncio.gather(*[limited(t) for t in tiles]))
+
+    async def process(self, input_path: str, output_path: str, prompt: str = "",
+                      roi_regions: Optional[List[Dict]] = None) -> PipelineResult:
+        start = time.time()
+        try:
+            # Stage 1: tiling
+            tiles = self.tiling_module.split_image(input_path)
+            # Stage 2: super-resolution of every tile
+            results = await self._parallel_upscale(tiles, prompt)
+            ok = [r for r in results if r is not None]
+            failed = len(results) - len(ok)
+            if not ok:
+                raise RuntimeError("所有分块处理失败")
+            s = self.config.sr_scale
+            step = self.tiling_module.block_size - self.tiling_module.overlap_pixels
+            infos = []
+            for tile, res in zip(tiles, results):
+                if res is not None:
+                    m = tile.metadata
+                    infos.append(TileInfo(res, m.global_x * s, m.global_y * s, m.global_y // step, m.global_x // step))
+            # Stage 3: blending (the canvas is cropped to the un-padded image, scaled)
+            from PIL import Image
+            with Image.open(input_path) as im:
+                iw, ih = im.size
+                original = np.asarray(im.convert("RGB"), dtype=np.uint8)
+            out_shape = (ih * s, iw * s)
+            if self.config.blend_method == 'weighted':
+                fused = self.blending_module.weighted_average_fusion(infos, output_shape=out_shape)
+            else:
+                fused = self.blending_module.laplacian_fusion(infos, None, output_shape=out_shape)
+            # Stage 4: quality assessment
+            report, score = None, None
+            if self.config.enable_qa:
+                qa = self.quality_module.evaluate_full_reference(original=original, upscaled=fused,
+                                                                 scale_factor=fused.shape[1] / original.shape[1])
+                report = {'full_reference': qa,
+                          'commercial': self.quality_module.evaluate_commercial(fused, roi_regions or []),
+                          'timestamp': datetime.now().isoformat()}
+                score = qa.get('overall_score', 0)
+            # Stage 5: output
+            Path(output_path).parent.mkdir(parents=True, exist_ok=True)
+            img = Image.fromarray(fused)
+            low = output_path.lower()
+            if low.endswith('.tiff') or low.endswith('.tif'):
+                img.save(output_path, format='TIFF', compression='tiff_lzw')
+            elif low.endswith('.png'):
+                img.save(output_path, format='PNG', compress_level=3)
+            else:
+                img.save(output_path, quality=95)
+            if report:
+                with open(output_path.rsplit('.', 1)[0] + '_qa_report.json', 'w', encoding='utf-8') as f:
+                    json.dump(report, f, indent=2, ensure_ascii=False, default=str)
+            return PipelineResult(True, output_path, time.time() - start, len(tiles), len(ok), failed, score, report, None)
+        except Exception as exc:  # noqa: BLE001 - the reference reports every failure in the result record
+            self.logger.error("Pipeline执行失败: %s", exc, exc_info=True)
+            return PipelineResult(False, None, time.time() - start, 0, 0, 0, None, None, str(exc))
+
+
+async def main():
+    import argparse
+    ap = argparse.ArgumentParser(description="tile -> bicubic-stub SR -> Laplacian blend -> QA on an MI355X")
+    ap.add_argument("input")
+    ap.add_argument("output")
+    ap.add_argument("--block-size", type=int, default=2048)
+    ap.add_argument("--sr-scale", type=int, default=2)
+    args = ap.parse_args()
+    logging.basicConfig(level=logging.INFO, stream=sys.stdout)
+    cfg = PipelineConfig(block_size=args.block_size, sr_scale=args.sr_scale)
+    async with SuperResolutionPipeline(cfg) as pipe:
+        res = await pipe.process(args.input, args.output, prompt="")
+    print(res)
+
+
+if __name__ == "__main__":
+    asyncio.run(main())

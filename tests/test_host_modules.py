@@ -1,0 +1,125 @@
+"""CPU: the host-side mirrors of the reference's modules -- names, defaults, enums, error behaviour
+and the pure bookkeeping (no GPU compute is called here)."""
+import dataclasses
+import os
+
+import numpy as np
+import pytest
+
+import blending_module as bm
+import main as sr_main
+import quality_assessment_module as qa
+import tiling_module as tm
+from oracle import oracle_np as onp
+
+
+def test_reference_names_exist():
+    for mod, names in [
+        (tm, ["PaddingMode", "TileStatus", "CacheLevel", "TileMetadata", "Tile", "LRUCache", "TilingModule"]),
+        (bm, ["FusionMethod", "PoissonMode", "WeightType", "Seam", "TileInfo", "OverlapRegion", "BlendingModule",
+              "create_tile_grid", "ParallelBlender"]),
+        (qa, ["AssessmentLevel", "QualityThresholds", "ScaleConfig", "QualityAssessmentModule"]),
+        (sr_main, ["PipelineConfig", "PipelineResult", "SuperResolutionPipeline"]),
+    ]:
+        for n in names:
+            assert hasattr(mod, n), (mod.__name__, n)
+
+
+def test_pipeline_config_defaults_match_reference():
+    c = sr_main.PipelineConfig()
+    ref = dict(block_size=2048, overlap_ratio=0.2, padding_mode='mirror', target_resolution="100MP",
+               seedream_strength=0.5, seedream_steps=50, blend_method='laplacian', num_pyramid_levels=6,
+               max_agents=60, max_concurrent=30, enable_qa=True, qa_device='cpu', volc_ak="", volc_sk="",
+               volc_region="cn-beijing")
+    for k, v in ref.items():
+        assert getattr(c, k) == v
+    assert [f.name for f in dataclasses.fields(sr_main.PipelineResult)] == [
+        "success", "output_path", "processing_time", "total_blocks", "successful_blocks", "failed_blocks",
+        "quality_score", "quality_report", "error_message"]
+
+
+def test_target_size_rule(tmp_path):
+    p = sr_main.SuperResolutionPipeline(sr_main.PipelineConfig(block_size=256))
+    p.tiling_module.l2_cache_dir  # constructed
+    assert p._calculate_target_size((1280, 720), "200MP") == (17320, 9742)
+    assert p._calculate_target_size((1080, 720), "200MP") == (17320, 11546)
+    assert p._calculate_target_size((1280, 720), "3000x2000") == (3000, 2000)
+    assert p._calculate_target_size((1280, 720), "bogus") == (12245, 8163)
+
+
+def test_tiling_module_init_rules(tmp_path):
+    with pytest.raises(ValueError):
+        tm.TilingModule(overlap_ratio=0.05, l2_cache_dir=str(tmp_path))
+    with pytest.raises(ValueError):
+        tm.TilingModule(overlap_ratio=0.35, l2_cache_dir=str(tmp_path))
+    with pytest.raises(ValueError):
+        tm.TilingModule(padding_mode="wrap", l2_cache_dir=str(tmp_path))
+    t = tm.TilingModule(block_size=1024, overlap_ratio=0.2, l2_cache_dir=str(tmp_path / "c"))
+    assert (t.overlap_pixels, t.output_size) == (204, 2048) and (tmp_path / "c").is_dir()
+    pos = t._calculate_tile_positions(4096, 4096)
+    assert len(pos) == 25 and pos[-1] == (3280, 3280, 816, 816)
+    assert t._calculate_overlap_for_tile(3280, 3280, 816, 816, 4096, 4096) == (204, 4, 204, 4)
+
+
+def test_tile_metadata_roundtrip_and_effective_region():
+    m = tm.TileMetadata(global_x=10, global_y=20, input_w=100, input_h=80, overlap_top=5, overlap_bottom=6,
+                        overlap_left=7, overlap_right=8)
+    d = m.to_dict()
+    assert d["status"] == "PENDING"
+    assert tm.TileMetadata.from_dict(d) == m
+    t = tm.Tile(metadata=m)
+    assert t.get_overlap_region() == (5, 6, 7, 8)
+    assert t.get_effective_region() == (17, 25, 17 + 100 - 15, 25 + 80 - 11)
+
+
+def test_lru_cache():
+    c = tm.LRUCache(max_size=2)
+    a, b, d = (tm.Tile(tm.TileMetadata()) for _ in range(3))
+    c.put("a", a); c.put("b", b); c.get("a"); c.put("d", d)
+    assert c.keys() == ["a", "d"] and c.get("b") is None and c.remove("a") and not c.remove("zz")
+
+
+def test_blending_module_config_and_grid():
+    with pytest.raises(ValueError):
+        bm.BlendingModule(method="nope")
+    b = bm.BlendingModule(method="weighted", num_levels=4)
+    assert b.method is bm.FusionMethod.WEIGHTED_AVERAGE and b.num_levels == 4
+    imgs = [np.zeros((48, 64, 3), np.uint8)] * 6
+    infos, regions = bm.create_tile_grid(imgs, (2, 3), overlap=10)
+    ref = onp.create_tile_grid_positions(6, (2, 3), (48, 64), 10)
+    assert [(i.x, i.y, i.row, i.col) for i in infos] == ref
+    want = onp.overlap_regions(ref, [(48, 64)] * 6)
+    got = [(r.tile1_idx, r.tile2_idx, r.x1_start, r.y1_start, r.x2_start, r.y2_start, r.width, r.height, r.direction)
+           for r in regions]
+    assert got == want and len(got) == 7
+    assert bm.Seam(0, 0, 1, 1, 0.80).severity == "high" and bm.Seam(0, 0, 1, 1, 0.99).suggested_fix == "none"
+    # weight map helper is the reference formula
+    for wt in bm.WeightType:
+        assert np.array_equal(b._create_distance_weight_map(40, 72, wt), onp.distance_weight_map(40, 72, wt.value))
+    # reference quirk: bare arrays without output_shape -> max() of an empty sequence
+    with pytest.raises(ValueError):
+        b.laplacian_fusion([np.zeros((32, 32, 3), np.uint8)])
+    with pytest.raises(NotImplementedError):
+        b.poisson_fusion(None, None)
+
+
+def test_qa_module_host_logic():
+    q = qa.QualityAssessmentModule()
+    assert q.lpips_model_vgg is None
+    assert q._assess_psnr(41) == "excellent" and q._assess_psnr(36) == "good" and q._assess_psnr(10) == "poor"
+    assert q._assess_ssim(0.97) == "good" and q._assess_lpips(0.2) == "poor"
+    assert q._calculate_overall_score({"psnr": 30.0, "ms_ssim": 0.9}) == pytest.approx(60.0)
+    assert q._calculate_overall_score({"psnr": 130.0, "ms_ssim": 0.9, "lpips_vgg": 0.5}) == pytest.approx(80.0)
+    assert q._calculate_overall_score({}) == 0.0
+    with pytest.raises(RuntimeError):
+        q.calculate_lpips(None, None)
+    with pytest.raises(ValueError):
+        q.downsample_bicubic(np.zeros((10, 10, 3), np.uint8), 1.5)
+    # preprocess rule: max <= 1.0 -> *255 -> u8 (incl. the all-black quirk)
+    assert q._preprocess_image(np.full((2, 2), 0.5)).dtype == np.uint8
+    assert q._preprocess_image(np.full((2, 2), 0.5))[0, 0] == 127
+    assert q._preprocess_image(np.zeros((2, 2), np.uint8)).dtype == np.uint8
+    a, b = q._crop_pair(np.zeros((5, 9, 3)), np.zeros((7, 4, 3)))
+    assert a.shape == b.shape == (5, 4, 3)
+    with pytest.raises(ValueError):
+        qa.QualityAssessmentModule(ssim_branch="C")
