@@ -98,12 +98,37 @@ SIGNATURES = {
 }
 
 
+def _preload_hip_runtime() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm wheels ship their own libamdhip64.so (SONAME
+    libamdhip64.so.7, like /opt/rocm's); if libsrhip.so pulled in the system copy first and torch is
+    imported later, two HIP/HSA runtimes would fight over the device ("No HIP GPUs are available").
+    Loading torch's copy by path first makes both resolve to the same object (glibc matches our NEEDED
+    entry by SONAME and torch's by inode).  Without torch installed the system runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load libsrhip.so (building it first if the sources are newer).  Raises SrNativeError."""
     global _lib
     with _lib_lock:
         if _lib is not None:
             return _lib
+        _preload_hip_runtime()
         if not os.path.exists(LIB_PATH):
             try:
                 from _build import build_native  # type: ignore

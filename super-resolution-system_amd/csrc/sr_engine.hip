@@ -20,6 +20,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -71,6 +72,23 @@ static hipError_t stream_sync(sr_ctx *c)
     return e;
 }
 
+// Live-handle registry: destroying a context destroys its plans; destroying (or using) a handle that is
+// no longer live is a harmless no-op / SR_ERR_INVALID_ARG instead of a use-after-free (host languages with
+// garbage collectors finalise objects in arbitrary order at shutdown).
+struct sr_blend_plan;
+static std::mutex g_reg_mu;
+static std::set<const void *> g_live_ctx, g_live_plan;
+static bool ctx_is_live(const sr_ctx *c)
+{
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    return c && g_live_ctx.count(c) != 0;
+}
+static bool plan_is_live(const sr_blend_plan *p)
+{
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    return p && g_live_plan.count(p) != 0;
+}
+
 static int ctx_scratch(sr_ctx *c, size_t bytes, void **out)
 {
     if (bytes > c->scratch_bytes) {
@@ -106,7 +124,7 @@ struct Guard {
 };
 
 #define CTX_ENTER(ctx)                                                               \
-    if (!(ctx)) return sr_set_error(SR_ERR_INVALID_ARG, "%s: null context", __func__); \
+    if (!ctx_is_live(ctx)) return sr_set_error(SR_ERR_INVALID_ARG, "%s: null or destroyed context", __func__); \
     Guard guard_(ctx);                                                               \
     if (!guard_.ok) return sr_set_error(SR_ERR_HIP, "%s: hipSetDevice(%d) failed", __func__, (ctx)->device)
 
@@ -867,6 +885,10 @@ static int ctx_create_impl(int device_id, void *stream, bool adopt, sr_ctx **out
         c->own_stream = true;
     }
     (void)hipSetDevice(prev);
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        g_live_ctx.insert(c);
+    }
     *out = c;
     return SR_OK;
 }
@@ -878,9 +900,16 @@ int sr_ctx_create_on_stream(int device_id, void *hip_stream, sr_ctx **out)
     return ctx_create_impl(device_id, hip_stream, true, out);
 }
 
+static std::vector<sr_blend_plan *> plans_of(sr_ctx *ctx);
+
 int sr_ctx_destroy(sr_ctx *ctx)
 {
-    if (!ctx) return SR_OK;
+    if (!ctx_is_live(ctx)) return SR_OK;
+    for (sr_blend_plan *p : plans_of(ctx)) sr_blend_plan_destroy(p);
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        g_live_ctx.erase(ctx);
+    }
     {
         Guard g(ctx);
         (void)hipStreamSynchronize(ctx->stream);
@@ -1126,9 +1155,22 @@ int sr_pyr_up_add(sr_ctx *ctx, const float *d_a, int h, int w, int cn, const flo
 }
 
 // ---- blend plan ------------------------------------------------------------------------------------
+static std::vector<sr_blend_plan *> plans_of(sr_ctx *ctx)
+{
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    std::vector<sr_blend_plan *> out;
+    for (const void *p : g_live_plan)
+        if (((const sr_blend_plan *)p)->ctx == ctx) out.push_back((sr_blend_plan *)p);
+    return out;
+}
+
 int sr_blend_plan_destroy(sr_blend_plan *plan)
 {
     if (!plan) return SR_OK;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        if (!g_live_plan.erase(plan)) return SR_OK;          // already destroyed (with its context)
+    }
     sr_ctx *ctx = plan->ctx;
     {
         Guard g(ctx);
@@ -1279,6 +1321,10 @@ int sr_blend_plan_create(sr_ctx *ctx, const sr_tile_rect *h_tiles, int n, int cn
     auto fail = [&](hipError_t e, const char *what) {
         int code = (e == hipErrorOutOfMemory) ? SR_ERR_OOM : SR_ERR_HIP;
         sr_set_error(code, "sr_blend_plan_create: %s: %s", what, hipGetErrorString(e));
+        {
+            std::lock_guard<std::mutex> lk(g_reg_mu);
+            g_live_plan.insert(P);
+        }
         sr_blend_plan_destroy(P);
         return code;
     };
@@ -1292,13 +1338,17 @@ int sr_blend_plan_create(sr_ctx *ctx, const sr_tile_rect *h_tiles, int n, int cn
     if ((e = hipMemcpyAsync(P->d_classes, P->classes.data(), sizeof(TileDev) * P->classes.size(), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e, "upload");
     if ((e = hipMemcpyAsync(P->d_luts, P->luts.data(), sizeof(float) * P->luts.size(), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e, "upload");
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(e, "sync");
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        g_live_plan.insert(P);
+    }
     *out = P;
     return SR_OK;
 }
 
 int sr_blend_plan_tile_rows(const sr_blend_plan *plan, int t, int *r0, int *r1)
 {
-    if (!plan || t < 0 || t >= plan->n || !r0 || !r1) return sr_set_error(SR_ERR_INVALID_ARG, "sr_blend_plan_tile_rows: bad args");
+    if (!plan_is_live(plan) || t < 0 || t >= plan->n || !r0 || !r1) return sr_set_error(SR_ERR_INVALID_ARG, "sr_blend_plan_tile_rows: bad args");
     *r0 = plan->tile_rows[t].a;
     *r1 = plan->tile_rows[t].b;
     return SR_OK;
@@ -1306,7 +1356,7 @@ int sr_blend_plan_tile_rows(const sr_blend_plan *plan, int t, int *r0, int *r1)
 
 int sr_blend_plan_workspace_bytes(const sr_blend_plan *plan, size_t *bytes)
 {
-    if (!plan || !bytes) return sr_set_error(SR_ERR_INVALID_ARG, "sr_blend_plan_workspace_bytes: bad args");
+    if (!plan_is_live(plan) || !bytes) return sr_set_error(SR_ERR_INVALID_ARG, "sr_blend_plan_workspace_bytes: bad args");
     *bytes = plan->arena_floats * sizeof(float);
     return SR_OK;
 }
@@ -1385,7 +1435,7 @@ static int blend_impl(sr_blend_plan *P, bool lap, int dtype, void *const *h_d_ti
 int sr_laplacian_blend(sr_blend_plan *plan, int dtype, void *const *h_d_tiles, const int64_t *h_strides,
                        uint8_t *d_canvas, int64_t canvas_stride, float *d_canvas_f32)
 {
-    if (!plan) return sr_set_error(SR_ERR_INVALID_ARG, "sr_laplacian_blend: null plan");
+    if (!plan_is_live(plan)) return sr_set_error(SR_ERR_INVALID_ARG, "sr_laplacian_blend: null or destroyed plan");
     CTX_ENTER(plan->ctx);
     return blend_impl(plan, true, dtype, h_d_tiles, h_strides, d_canvas, canvas_stride, d_canvas_f32);
 }
@@ -1393,7 +1443,7 @@ int sr_laplacian_blend(sr_blend_plan *plan, int dtype, void *const *h_d_tiles, c
 int sr_weighted_blend(sr_blend_plan *plan, int dtype, void *const *h_d_tiles, const int64_t *h_strides,
                       uint8_t *d_canvas, int64_t canvas_stride, float *d_canvas_f32)
 {
-    if (!plan) return sr_set_error(SR_ERR_INVALID_ARG, "sr_weighted_blend: null plan");
+    if (!plan_is_live(plan)) return sr_set_error(SR_ERR_INVALID_ARG, "sr_weighted_blend: null or destroyed plan");
     CTX_ENTER(plan->ctx);
     return blend_impl(plan, false, dtype, h_d_tiles, h_strides, d_canvas, canvas_stride, d_canvas_f32);
 }
