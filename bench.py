@@ -56,10 +56,8 @@ def algorithmic_bytes(geo) -> dict:
         "down_l1p": (12.0 * s14 + 12.0 * s25) * n,                 # G1..G4 in, G2..G5 out
         "up_level": (34.0 * s14 + 28.0 * 4.0 ** -5) * n,           # G_i, G_i+1/4, R_i+1/4, W_i in; R_i out
         "final_gather": 9.0 * n + 3.0 * m,                         # u8 tile + G1/4 + R1/4 in; u8 canvas out
-        "psnr_sse": 6.0 * m,
-        "ssim_uniform7": 6.0 * m,
-        "ssim_gauss11": 6.0 * m,
-        "ssim_simple": 6.0 * m,
+        "assess_gauss_sse": 6.0 * m,                               # both u8 images once: SSE + gauss11 + simple
+        "assess_uniform": 6.0 * m,                                 # both u8 images once: uniform-7 (integer)
         # the reference-shaped model of SURVEY 8(d) (scatter into fp32 accumulators), for comparison
         "_survey_blend_model": 63.30 * n + 19.0 * m,
     }

@@ -208,6 +208,26 @@ SR_API int sr_ssim_u8_async(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, c
                             int64_t stride_b, int h, int w, int cn, int mode, int gray_shift,
                             double data_range, int row_begin, int row_end, double *d_sum,
                             uint64_t *h_count);
+/* Fused assessment: ONE pass over both images (6 bytes / pixel) for the squared-difference sum and
+ * the Gaussian SSIM in both variants (cropped "gauss11" and full-frame REFLECT_101 "simple" share all
+ * filtered values), plus an all-integer pass for the uniform-7 variant.  Every field is a partial sum over
+ * rows [row_begin,row_end) -- additive across strips; divide by sr_ssim_count / (h*w*cn).  The record
+ * is all fp64 (the SSE is an exact integer < 2^53) so a strip owner can all-reduce it as is. */
+enum sr_assess_flags { SR_ASSESS_SSE = 1, SR_ASSESS_UNIFORM7 = 2, SR_ASSESS_GAUSS11 = 4, SR_ASSESS_SIMPLE = 8, SR_ASSESS_ALL = 15 };
+typedef struct sr_assess_sums {
+    double sse;
+    double ssim_uniform;
+    double ssim_gauss;
+    double ssim_simple;
+} sr_assess_sums;
+SR_API int sr_assess_u8_async(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uint8_t *d_b,
+                              int64_t stride_b, int h, int w, int cn, int gray_shift, double data_range,
+                              int row_begin, int row_end, int flags, sr_assess_sums *d_out);
+SR_API int sr_assess_u8(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uint8_t *d_b,
+                        int64_t stride_b, int h, int w, int cn, int gray_shift, double data_range,
+                        int row_begin, int row_end, int flags, sr_assess_sums *h_out);
+/* number of SSIM-map samples of `mode` inside rows [row_begin,row_end) (host only) */
+SR_API int sr_ssim_count(int h, int w, int mode, int row_begin, int row_end, uint64_t *count);
 /* cv2.cvtColor(RGB2GRAY) on u8 (quality_assessment_module.py:359-360) */
 SR_API int sr_rgb2gray_u8(sr_ctx *ctx, const uint8_t *d_rgb, int64_t stride, int h, int w,
                           int gray_shift, uint8_t *d_gray, int64_t gray_stride);

@@ -39,6 +39,14 @@ class MergeTile(C.Structure):
                                         "ov_t", "ov_b", "ov_l", "ov_r")]
 
 
+class AssessSums(C.Structure):
+    _fields_ = [("sse", C.c_double), ("ssim_uniform", C.c_double), ("ssim_gauss", C.c_double),
+                ("ssim_simple", C.c_double)]
+
+
+ASSESS_SSE, ASSESS_UNIFORM7, ASSESS_GAUSS11, ASSESS_SIMPLE, ASSESS_ALL = 1, 2, 4, 8, 15
+
+
 class ProfRecord(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("ms", C.c_double), ("launches", C.c_int64)]
 
@@ -92,6 +100,9 @@ SIGNATURES = {
     "sr_psnr_from_sse": (_dbl, [C.c_uint64, C.c_uint64, _dbl]),
     "sr_ssim_u8": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _dbl, _i, _i, C.POINTER(_dbl), C.POINTER(C.c_uint64)]),
     "sr_ssim_u8_async": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _dbl, _i, _i, _vp, C.POINTER(C.c_uint64)]),
+    "sr_assess_u8_async": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _dbl, _i, _i, _i, _vp]),
+    "sr_assess_u8": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _dbl, _i, _i, _i, C.POINTER(AssessSums)]),
+    "sr_ssim_count": (_i, [_i, _i, _i, _i, _i, C.POINTER(C.c_uint64)]),
     "sr_rgb2gray_u8": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _i64]),
     "sr_resize_cubic_u8": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _i64, _i, _i]),
     "sr_resize_cubic_window_u8": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64]),
@@ -224,6 +235,12 @@ def strip_tile_rows(rects_xywh, levels: int, canvas_h: int, row_begin: int, row_
     return [(out[2 * i], out[2 * i + 1]) for i in range(n)]
 
 
+def ssim_count(h: int, w: int, mode: str, row_begin: int = 0, row_end: Optional[int] = None) -> int:
+    n = C.c_uint64(0)
+    check(load().sr_ssim_count(h, w, SSIM_MODES[mode], row_begin, h if row_end is None else row_end, C.byref(n)))
+    return n.value
+
+
 def psnr_from_sse(sse: int, count: int, data_range: float = 255.0) -> float:
     return float(load().sr_psnr_from_sse(C.c_uint64(sse), C.c_uint64(count), data_range))
 
@@ -351,6 +368,22 @@ class Context:
                                         SSIM_MODES[mode], gray_shift, data_range, row_begin,
                                         h if row_end is None else row_end, C.c_void_p(d_sum), C.byref(n)))
         return n.value
+
+    def assess_u8_async(self, d_a, stride_a, d_b, stride_b, h, w, cn, d_out: int, flags=ASSESS_ALL, gray_shift=15,
+                        data_range=255.0, row_begin=0, row_end=None):
+        """Fused PSNR-SSE + SSIM partial sums -> 4 doubles at d_out (sse, uniform, gauss, simple); no sync."""
+        check(self.lib.sr_assess_u8_async(self.handle, C.c_void_p(d_a), stride_a, C.c_void_p(d_b), stride_b, h, w, cn,
+                                          gray_shift, data_range, row_begin, h if row_end is None else row_end,
+                                          flags, C.c_void_p(d_out)))
+
+    def assess_u8(self, d_a, stride_a, d_b, stride_b, h, w, cn, flags=ASSESS_ALL, gray_shift=15, data_range=255.0,
+                  row_begin=0, row_end=None) -> dict:
+        out = AssessSums()
+        check(self.lib.sr_assess_u8(self.handle, C.c_void_p(d_a), stride_a, C.c_void_p(d_b), stride_b, h, w, cn,
+                                    gray_shift, data_range, row_begin, h if row_end is None else row_end, flags,
+                                    C.byref(out)))
+        return {"sse": out.sse, "ssim_uniform": out.ssim_uniform, "ssim_gauss": out.ssim_gauss,
+                "ssim_simple": out.ssim_simple}
 
     def rgb2gray_u8(self, d_rgb, stride, h, w, d_gray, gray_stride, gray_shift=15):
         check(self.lib.sr_rgb2gray_u8(self.handle, C.c_void_p(d_rgb), stride, h, w, gray_shift, C.c_void_p(d_gray),

@@ -236,6 +236,8 @@ struct TileDev {
     int r0[SR_MAX_LEVELS], r1[SR_MAX_LEVELS];  // R row windows
 };
 
+static_assert(sizeof(TileDev) % 16 == 0, "k_final_blk reads the leading {h,w,x,y} as one int4");
+
 struct TileSrc {
     const void *p;
     long long stride;
@@ -382,6 +384,329 @@ __global__ __launch_bounds__(256) void k_final(const TileDev *__restrict__ tiles
         if (canvas_f32) canvas_f32[((size_t)y * cw + x) * cn + c] = v;
         const float cl = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
         o[c] = (unsigned char)cl;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Final gather, register-blocked: one thread = 4 x 2 canvas pixels.  For every covering tile the
+// thread loads ONE 3-row x 4-column neighbourhood of G_1 and R_1 per plane and evaluates the same
+// per-pixel expressions as k_final from registers (12 loads per 8 pixels per plane per array
+// instead of 6-9 per pixel).  x0 is a multiple of 4 and y0 - row_begin a multiple of 2, so the
+// parity of the tile-local origin -- which selects the even/odd pyrUp phase of every pixel in the
+// thread -- is uniform per tile across the launch (template XO / YO).
+// ---------------------------------------------------------------------------------------------
+template <int POS, bool ODD>
+__device__ __forceinline__ float up_h_reg(const float (&v)[4], int ws, int sx)
+{
+    if (ws == 1) return ODD ? v[POS] * 8.0f : v[POS] * 6.0f + v[POS] * 2.0f;
+    if (!ODD) {
+        constexpr int PM = POS > 0 ? POS - 1 : 0;
+        if (sx == 0) return v[POS] * 6.0f + v[POS + 1] * 2.0f;
+        if (sx == ws - 1) return v[PM] + v[POS] * 7.0f;
+        return (v[PM] + v[POS] * 6.0f) + v[POS + 1];
+    }
+    constexpr int PP = POS < 3 ? POS + 1 : 3;
+    if (sx == ws - 1) return v[POS] * 8.0f;
+    return (v[POS] + v[PP]) * 4.0f;
+}
+
+// h[r][k]: unnormalised horizontal pyrUp of loaded row r at thread pixel k
+template <bool XO>
+__device__ __forceinline__ void up_rows4(const float (&v)[3][4], int ws, int c0, float (&h)[3][4])
+{
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        if (!XO) {
+            h[r][0] = up_h_reg<1, false>(v[r], ws, c0 + 1);
+            h[r][1] = up_h_reg<1, true>(v[r], ws, c0 + 1);
+            h[r][2] = up_h_reg<2, false>(v[r], ws, c0 + 2);
+            h[r][3] = up_h_reg<2, true>(v[r], ws, c0 + 2);
+        } else {
+            h[r][0] = up_h_reg<0, true>(v[r], ws, c0);
+            h[r][1] = up_h_reg<1, false>(v[r], ws, c0 + 1);
+            h[r][2] = up_h_reg<1, true>(v[r], ws, c0 + 1);
+            h[r][3] = up_h_reg<2, false>(v[r], ws, c0 + 2);
+        }
+    }
+}
+
+// vertical combination for the thread's two rows (j = 0, 1) at pixel column k
+template <bool YO>
+__device__ __forceinline__ void up_cols2(const float (&h)[3][4], int r0, float (&u)[2][4])
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (!YO) {
+            // j = 0: even row, sy = r0 + 1;  j = 1: odd row, sy = r0 + 1
+            const float top = (r0 + 1 == 0) ? h[2][k] : h[0][k];
+            u[0][k] = ((top + h[1][k] * 6.0f) + h[2][k]) * (1.0f / 64.0f);
+            u[1][k] = ((h[1][k] + h[2][k]) * 4.0f) * (1.0f / 64.0f);
+        } else {
+            // j = 0: odd row, sy = r0;  j = 1: even row, sy = r0 + 1
+            const float top = (r0 + 1 == 0) ? h[2][k] : h[0][k];
+            u[0][k] = ((h[0][k] + h[1][k]) * 4.0f) * (1.0f / 64.0f);
+            u[1][k] = ((top + h[1][k] * 6.0f) + h[2][k]) * (1.0f / 64.0f);
+        }
+    }
+}
+
+template <bool XO, bool YO>
+__device__ __forceinline__ void up_block(const float *__restrict__ plane, int hs, int ws, int ps, int r0, int c0,
+                                         float (&u)[2][4])
+{
+    float v[3][4], h[3][4];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float *row = plane + (size_t)min(max(r0 + r, 0), hs - 1) * ps;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[r][c] = row[min(max(c0 + c, 0), ws - 1)];
+    }
+    up_rows4<XO>(v, ws, c0, h);
+    up_cols2<YO>(h, r0, u);
+}
+
+struct __attribute__((packed, aligned(4))) F4A {
+    float v[4];
+};
+struct __attribute__((packed, aligned(1))) U96 {
+    unsigned a, b, c;
+};
+
+// interior form of up_block: every pixel of the thread is away from the level-1 borders, so the
+// border selects of up_h / the row clamps vanish; same expressions as the generic path otherwise
+template <bool XO, bool YO>
+__device__ __forceinline__ void up_block_interior(const float *__restrict__ plane, int ps, int r0, int c0,
+                                                  float (&u)[2][4])
+{
+    float h[3][4];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const F4A q = *(const F4A *)(plane + (size_t)(r0 + r) * ps + c0);
+        if (!XO) {
+            h[r][0] = (q.v[0] + q.v[1] * 6.0f) + q.v[2];
+            h[r][1] = (q.v[1] + q.v[2]) * 4.0f;
+            h[r][2] = (q.v[1] + q.v[2] * 6.0f) + q.v[3];
+            h[r][3] = (q.v[2] + q.v[3]) * 4.0f;
+        } else {
+            h[r][0] = (q.v[0] + q.v[1]) * 4.0f;
+            h[r][1] = (q.v[0] + q.v[1] * 6.0f) + q.v[2];
+            h[r][2] = (q.v[1] + q.v[2]) * 4.0f;
+            h[r][3] = (q.v[1] + q.v[2] * 6.0f) + q.v[3];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float ev = ((h[0][k] + h[1][k] * 6.0f) + h[2][k]) * (1.0f / 64.0f);
+        if (!YO) {
+            u[0][k] = ev;
+            u[1][k] = ((h[1][k] + h[2][k]) * 4.0f) * (1.0f / 64.0f);
+        } else {
+            u[0][k] = ((h[0][k] + h[1][k]) * 4.0f) * (1.0f / 64.0f);
+            u[1][k] = ev;
+        }
+    }
+}
+
+template <int DT, bool LAP, int CN, bool XO, bool YO>
+__device__ __forceinline__ void gather_tile(const TileDev &T, const TileSrc S, const float *__restrict__ arena,
+                                            const float *__restrict__ luts, int lx0, int ly0, unsigned valid,
+                                            float (&acc)[2][4][CN], float (&wacc)[2][4])
+{
+    float w0[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int lx = lx0 + k, ly = ly0 + j;
+            const int d = min(min(ly, T.h - 1 - ly), min(lx, T.w - 1 - lx));
+            w0[j][k] = luts[T.lut_off + min(max(d, 0), T.fw)];
+        }
+    const int r0 = (ly0 - 1) >> 1, c0 = (lx0 - 1) >> 1;
+    const bool pyr = LAP && T.nl > 1;
+    const int hs = T.H[1], ws = T.W[1], ps = T.P[1];
+    const size_t splane = (size_t)hs * ps;
+    // ---- interior fast path (the overwhelming majority of threads) ------------------------------
+    if (valid == 0xFFu && (!pyr || (c0 >= 0 && c0 + 3 <= ws - 1 && r0 >= 0 && r0 + 2 <= hs - 1))) {
+        float g0[2][4][CN];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const char *srow = (const char *)S.p + (size_t)(ly0 + j) * S.stride;
+            if (DT == SRC_U8 && CN == 3) {
+                const U96 q = *(const U96 *)(srow + (size_t)lx0 * 3);
+                const unsigned wds[3] = {q.a, q.b, q.c};
+#pragma unroll
+                for (int b = 0; b < 12; ++b) g0[j][b / 3][b % 3] = (float)((wds[b >> 2] >> (8 * (b & 3))) & 0xFFu);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int c = 0; c < CN; ++c) {
+                        if (DT == SRC_U8) g0[j][k][c] = (float)((const unsigned char *)srow)[(lx0 + k) * CN + c];
+                        else g0[j][k][c] = ((const float *)srow)[(lx0 + k) * CN + c];
+                    }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CN; ++c) {
+            float ug[2][4], ur[2][4];
+            if (pyr) {
+                up_block_interior<XO, YO>(arena + T.g_off[1] + c * splane, ps, r0, c0, ug);
+                up_block_interior<XO, YO>(arena + T.r_off[1] + c * splane, ps, r0, c0, ur);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float r;
+                    if (pyr) {
+                        const float lap = g0[j][k][c] - ug[j][k];
+                        const float wl = lap * w0[j][k];
+                        r = ur[j][k] + wl;
+                    } else {
+                        r = g0[j][k][c] * w0[j][k];
+                    }
+                    acc[j][k][c] += r;
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wacc[j][k] += w0[j][k];
+        return;
+    }
+    // ---- generic path: tile / level borders and partially covered threads ---------------------------
+#pragma unroll 1
+    for (int c = 0; c < CN; ++c) {
+        float ug[2][4], ur[2][4];
+        if (pyr) {
+            up_block<XO, YO>(arena + T.g_off[1] + c * splane, hs, ws, ps, r0, c0, ug);
+            up_block<XO, YO>(arena + T.r_off[1] + c * splane, hs, ws, ps, r0, c0, ur);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!(valid & (1u << (j * 4 + k)))) continue;
+                const char *srow = (const char *)S.p + (size_t)(ly0 + j) * S.stride;
+                float g0;
+                if (DT == SRC_U8) g0 = (float)((const unsigned char *)srow)[(lx0 + k) * CN + c];
+                else g0 = ((const float *)srow)[(lx0 + k) * CN + c];
+                float r;
+                if (pyr) {
+                    const float lap = g0 - ug[j][k];
+                    const float wl = lap * w0[j][k];
+                    r = ur[j][k] + wl;
+                } else {
+                    r = g0 * w0[j][k];
+                }
+                acc[j][k][c] += r;
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (valid & (1u << (j * 4 + k))) wacc[j][k] += w0[j][k];
+}
+
+#define FINAL_MAX_CAND 64
+
+template <int DT, bool LAP, int CN>
+__global__ __launch_bounds__(256) void k_final_blk(const TileDev *__restrict__ tiles, const TileSrc *__restrict__ srcs,
+                                                   int n, const float *__restrict__ arena,
+                                                   const float *__restrict__ luts, unsigned char *__restrict__ canvas,
+                                                   long long cstride, float *__restrict__ canvas_f32, int cw,
+                                                   int row_begin, int row_end)
+{
+    // ---- candidate tiles of this block (256 x 8 pixel footprint), in list order --------------------
+    __shared__ int s_cnt;
+    __shared__ int s_list[FINAL_MAX_CAND];
+    const int bx0 = blockIdx.x * 256, by0 = row_begin + blockIdx.y * 8;
+    const int bx1 = min(bx0 + 256, cw), by1 = min(by0 + 8, row_end);
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    if (tid < 64) {
+        int cnt = 0;
+        for (int base = 0; base < n; base += 64) {
+            const int t = base + tid;
+            bool hit = false;
+            if (t < n) {
+                const int4 r = *(const int4 *)&tiles[t];      // h, w, x, y
+                hit = r.z < bx1 && r.z + r.y > bx0 && r.w < by1 && r.w + r.x > by0;
+            }
+            const unsigned long long m = __ballot(hit);
+            if (hit) {
+                const int pos = cnt + __popcll(m & ((1ull << tid) - 1ull));
+                if (pos < FINAL_MAX_CAND) s_list[pos] = t;
+            }
+            cnt += __popcll(m);
+        }
+        if (tid == 0) s_cnt = cnt;
+    }
+    __syncthreads();
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y0 = row_begin + (blockIdx.y * 4 + threadIdx.y) * 2;
+    if (x0 >= cw || y0 >= row_end) return;
+    float acc[2][4][CN], wacc[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            wacc[j][k] = 0.f;
+#pragma unroll
+            for (int c = 0; c < CN; ++c) acc[j][k][c] = 0.f;
+        }
+    const int nx = min(4, cw - x0), ny = min(2, row_end - y0);
+    const int ncand = s_cnt;
+    const bool overflow = ncand > FINAL_MAX_CAND;           // pathological overlap: walk every tile
+    const int nloop = overflow ? n : ncand;
+    for (int i = 0; i < nloop; ++i) {
+        const int t = overflow ? i : s_list[i];
+        const TileDev &T = tiles[t];
+        const int lx0 = x0 - T.x, ly0 = y0 - T.y;
+        if (lx0 + nx <= 0 || ly0 + ny <= 0 || lx0 >= T.w || ly0 >= T.h) continue;
+        unsigned valid = 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (j < ny && k < nx && lx0 + k >= 0 && lx0 + k < T.w && ly0 + j >= 0 && ly0 + j < T.h)
+                    valid |= 1u << (j * 4 + k);
+        const bool xo = (T.x & 1) != 0;                      // x0 is a multiple of 4
+        const bool yo = ((row_begin - T.y) & 1) != 0;        // y0 - row_begin is a multiple of 2
+        const TileSrc S = srcs[t];
+        if (!xo && !yo) gather_tile<DT, LAP, CN, false, false>(T, S, arena, luts, lx0, ly0, valid, acc, wacc);
+        else if (xo && !yo) gather_tile<DT, LAP, CN, true, false>(T, S, arena, luts, lx0, ly0, valid, acc, wacc);
+        else if (!xo && yo) gather_tile<DT, LAP, CN, false, true>(T, S, arena, luts, lx0, ly0, valid, acc, wacc);
+        else gather_tile<DT, LAP, CN, true, true>(T, S, arena, luts, lx0, ly0, valid, acc, wacc);
+    }
+    const bool vec_ok = (CN == 3) && nx == 4 && ((cstride & 3) == 0) && ((((size_t)canvas) & 3) == 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (j >= ny) break;
+        unsigned char ob[4 * CN];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float wv = wacc[j][k] > 1e-6f ? wacc[j][k] : 1e-6f;
+#pragma unroll
+            for (int c = 0; c < CN; ++c) {
+                const float v = acc[j][k][c] / wv;
+                if (canvas_f32 && k < nx) canvas_f32[((size_t)(y0 + j) * cw + x0 + k) * CN + c] = v;
+                const float cl = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
+                ob[k * CN + c] = (unsigned char)cl;
+            }
+        }
+        unsigned char *o = canvas + (size_t)(y0 + j) * cstride + (size_t)x0 * CN;
+        if (vec_ok) {
+            unsigned int *o32 = (unsigned int *)o;
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                o32[q] = (unsigned)ob[4 * q] | ((unsigned)ob[4 * q + 1] << 8) | ((unsigned)ob[4 * q + 2] << 16) |
+                         ((unsigned)ob[4 * q + 3] << 24);
+        } else {
+            for (int k = 0; k < nx; ++k)
+#pragma unroll
+                for (int c = 0; c < CN; ++c) o[k * CN + c] = ob[k * CN + c];
+        }
     }
 }
 
@@ -567,100 +892,298 @@ __global__ __launch_bounds__(256) void k_rgb2gray(const unsigned char *__restric
     gray[(size_t)y * gstride + x] = (unsigned char)gray_of(rgb + (size_t)y * stride + (size_t)x * 3, 3, shift);
 }
 
-// SSIM.  One block = SS_TX x SS_TY map samples.  Gray halo tile in LDS, separable fp64 filter
-// (rows pass into LDS, then columns), SSIM formula, block sum -> partials[block].
-#define SS_TX 32
-#define SS_TY 16
-#define SS_R 5  // max radius (11 taps)
+// ---------------------------------------------------------------------------------------------
+// Fused assessment kernels.
+//
+// k_assess_gauss: one pass over both u8 images (6 B / pixel) producing, per block,
+//   * the sum of squared differences of its interior pixels (PSNR),
+//   * the sum of the Gaussian-11 SSIM map over the cropped (valid) region  -> "gauss"  (branch A)
+//   * the sum of the same map over the full frame with REFLECT_101 borders -> "simple" (branch B)
+// The two SSIM variants share every filtered value: scipy's gaussian_filter(sigma 1.5, truncate 3.5)
+// and cv2.GaussianBlur((11,11), 1.5) are the same normalised kernel, they differ only in border rule
+// and crop.  fp64 throughout (reference numerics); the row pass works on exact integers: gray values,
+// (x+y)^2 and (x-y)^2 are ints, symmetric taps are pair-summed as ints and only 6 products per map are
+// formed.  4 filtered maps (x, y, (x+y)^2, (x-y)^2) replace the reference's 5:
+//   uxx + uyy = (P + Q) / 2,  uxy = (P - Q) / 4.
+//
+// k_assess_uniform: the uniform 7x7 variant entirely in integers (window sums are exact), fp64 only
+// for the final formula.
+// ---------------------------------------------------------------------------------------------
+#define AG_TX 32
+#define AG_TY 54
+#define AG_R 5
+#define AG_ROWS (AG_TY + 2 * AG_R) /* 64 */
+#define AG_COLS (AG_TX + 2 * AG_R) /* 42 */
+#define AG_GP 44                   /* gray row pitch (bytes)  */
+#define AG_HP 33                   /* H row pitch (doubles)   */
 
-struct SsimParams {
-    int h, w, cn, shift;
-    int klen, rad, bmode;      // filter taps, radius, border rule for taps outside the image
-    int vy0, vy1, vx0, vx1;    // map region summed (valid region ∩ row range)
-    double cov_norm, c1, c2;
-    double k[11];
+enum { ASSESS_SSE = 1, ASSESS_UNIFORM = 2, ASSESS_GAUSS = 4, ASSESS_SIMPLE = 8 };
+
+struct AssessParams {
+    int h, w, shift, ry0, ry1, flags, same_c;
+    double c1a, c2a;   // constants for data_range (uniform / gauss)
+    double c1b, c2b;   // constants for 255 (simple)
+    double k[6];       // k[0] centre tap, k[j] the +-j taps
 };
 
-__global__ __launch_bounds__(256) void k_ssim(const unsigned char *__restrict__ a, long long sa,
-                                              const unsigned char *__restrict__ b, long long sb, SsimParams P,
-                                              double *__restrict__ partials)
+template <int CN>
+__device__ __forceinline__ void load_gray_pair(const unsigned char *__restrict__ a, long long sa,
+                                               const unsigned char *__restrict__ b, long long sb, int sy, int sx,
+                                               int shift, int &ga, int &gb, unsigned &sq)
 {
-    __shared__ unsigned char gx[SS_TY + 2 * SS_R][SS_TX + 2 * SS_R];
-    __shared__ unsigned char gy[SS_TY + 2 * SS_R][SS_TX + 2 * SS_R];
-    __shared__ double hb[5][SS_TY + 2 * SS_R][SS_TX];
-    __shared__ double wsum[4];
-    const int tid = threadIdx.x;
-    const int bx0 = P.vx0 + blockIdx.x * SS_TX, by0 = P.vy0 + blockIdx.y * SS_TY;
-    const int R = P.rad;
-    const int TW = SS_TX + 2 * R, TH = SS_TY + 2 * R;
-    for (int i = tid; i < TW * TH; i += 256) {
-        const int ly = i / TW, lx = i - ly * TW;
-        const int sy = border_index(by0 + ly - R, P.h, P.bmode);
-        const int sx = border_index(bx0 + lx - R, P.w, P.bmode);
-        gx[ly][lx] = (unsigned char)gray_of(a + (size_t)sy * sa + (size_t)sx * P.cn, P.cn, P.shift);
-        gy[ly][lx] = (unsigned char)gray_of(b + (size_t)sy * sb + (size_t)sx * P.cn, P.cn, P.shift);
-    }
-    __syncthreads();
-    for (int i = tid; i < SS_TX * TH; i += 256) {
-        const int ly = i / SS_TX, lx = i - ly * SS_TX;
-        double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
-        for (int j = 0; j < P.klen; ++j) {
-            const int xv = gx[ly][lx + j], yv = gy[ly][lx + j];
-            const double kw = P.k[j];
-            s0 += (double)xv * kw;
-            s1 += (double)yv * kw;
-            s2 += (double)(xv * xv) * kw;
-            s3 += (double)(yv * yv) * kw;
-            s4 += (double)(xv * yv) * kw;
+    const unsigned char *pa = a + (size_t)sy * sa + (size_t)sx * CN;
+    const unsigned char *pb = b + (size_t)sy * sb + (size_t)sx * CN;
+    if (CN == 1) {
+        ga = pa[0];
+        gb = pb[0];
+        const int d = ga - gb;
+        sq = (unsigned)(d * d);
+    } else {
+        const int r0 = pa[0], g0 = pa[1], b0 = pa[2], r1 = pb[0], g1 = pb[1], b1 = pb[2];
+        if (shift == 15) {
+            ga = (r0 * 9798 + g0 * 19235 + b0 * 3735 + (1 << 14)) >> 15;
+            gb = (r1 * 9798 + g1 * 19235 + b1 * 3735 + (1 << 14)) >> 15;
+        } else {
+            ga = (r0 * 4899 + g0 * 9617 + b0 * 1868 + (1 << 13)) >> 14;
+            gb = (r1 * 4899 + g1 * 9617 + b1 * 1868 + (1 << 13)) >> 14;
         }
-        hb[0][ly][lx] = s0;
-        hb[1][ly][lx] = s1;
-        hb[2][ly][lx] = s2;
-        hb[3][ly][lx] = s3;
-        hb[4][ly][lx] = s4;
+        const int dr = r0 - r1, dg = g0 - g1, db = b0 - b1;
+        sq = (unsigned)(dr * dr + dg * dg + db * db);
     }
-    __syncthreads();
-    double local = 0.0;
-    for (int i = tid; i < SS_TX * SS_TY; i += 256) {
-        const int ly = i / SS_TX, lx = i - ly * SS_TX;
-        const int my = by0 + ly, mx = bx0 + lx;
-        if (my >= P.vy1 || mx >= P.vx1) continue;
-        double ux = 0, uy = 0, uxx = 0, uyy = 0, uxy = 0;
-        for (int j = 0; j < P.klen; ++j) {
-            const double kw = P.k[j];
-            ux += hb[0][ly + j][lx] * kw;
-            uy += hb[1][ly + j][lx] * kw;
-            uxx += hb[2][ly + j][lx] * kw;
-            uyy += hb[3][ly + j][lx] * kw;
-            uxy += hb[4][ly + j][lx] * kw;
-        }
-        const double vx = P.cov_norm * (uxx - ux * ux);
-        const double vy = P.cov_norm * (uyy - uy * uy);
-        const double vxy = P.cov_norm * (uxy - ux * uy);
-        const double a1 = 2 * ux * uy + P.c1, a2 = 2 * vxy + P.c2;
-        const double b1 = ux * ux + uy * uy + P.c1, b2 = vx + vy + P.c2;
-        local += (a1 * a2) / (b1 * b2);
-    }
-    local = wave_sum_f64(local);
-    if ((tid & 63) == 0) wsum[tid >> 6] = local;
-    __syncthreads();
-    if (tid == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
 }
 
-// deterministic final sum of the per-block partials (fixed order)
-__global__ __launch_bounds__(256) void k_sum_partials(const double *__restrict__ partials, int n,
-                                                      double *__restrict__ out)
+__device__ __forceinline__ double ssim_value(double ux, double uy, double spq, double dpq, double c1, double c2)
+{
+    // spq = (P + Q) / 2 = uxx + uyy,  dpq = (P - Q) / 4 = uxy
+    const double uxuy = ux * uy, uu = ux * ux + uy * uy;
+    const double a1 = 2.0 * uxuy + c1, a2 = 2.0 * (dpq - uxuy) + c2;
+    const double b1 = uu + c1, b2 = (spq - uu) + c2;
+    return (a1 * a2) / (b1 * b2);
+}
+
+template <int CN>
+__global__ __launch_bounds__(256) void k_assess_gauss(const unsigned char *__restrict__ a, long long sa,
+                                                      const unsigned char *__restrict__ b, long long sb,
+                                                      AssessParams P, double *__restrict__ part)
+{
+    __shared__ unsigned char gxs[AG_ROWS][AG_GP], gys[AG_ROWS][AG_GP];
+    __shared__ double H[4][AG_ROWS][AG_HP];
+    __shared__ double red[4][3];
+    const int tid = threadIdx.x;
+    const int bx0 = blockIdx.x * AG_TX, by0 = P.ry0 + blockIdx.y * AG_TY;
+    // ---- phase 1: gray halo tile (REFLECT_101 outside the image) + squared differences -----------
+    unsigned long long sse = 0;
+    for (int i = tid; i < AG_ROWS * AG_COLS; i += 256) {
+        const int ly = i / AG_COLS, lx = i - ly * AG_COLS;
+        const int gy = by0 - AG_R + ly, gx = bx0 - AG_R + lx;
+        const int sy = reflect101(gy, P.h), sx = reflect101(gx, P.w);
+        int ga, gb;
+        unsigned sq;
+        load_gray_pair<CN>(a, sa, b, sb, sy, sx, P.shift, ga, gb, sq);
+        gxs[ly][lx] = (unsigned char)ga;
+        gys[ly][lx] = (unsigned char)gb;
+        if (ly >= AG_R && ly < AG_R + AG_TY && lx >= AG_R && lx < AG_R + AG_TX && gy < P.ry1 && gy < P.h && gx < P.w)
+            sse += sq;
+    }
+    __syncthreads();
+    // ---- phase 2: row pass, thread = (row, 8 output columns) ---------------------------------------
+    {
+        const int row = tid >> 2, g = tid & 3;
+        int xv[18], yv[18], pv[18], qv[18];
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+            xv[i] = gxs[row][8 * g + i];
+            yv[i] = gys[row][8 * g + i];
+            const int sm = xv[i] + yv[i], df = xv[i] - yv[i];
+            pv[i] = sm * sm;
+            qv[i] = df * df;
+        }
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            const int c = o + AG_R;
+            double hx = (double)xv[c] * P.k[0], hy = (double)yv[c] * P.k[0];
+            double hp = (double)pv[c] * P.k[0], hq = (double)qv[c] * P.k[0];
+#pragma unroll
+            for (int j = 1; j <= AG_R; ++j) {
+                hx = fma((double)(xv[c - j] + xv[c + j]), P.k[j], hx);
+                hy = fma((double)(yv[c - j] + yv[c + j]), P.k[j], hy);
+                hp = fma((double)(pv[c - j] + pv[c + j]), P.k[j], hp);
+                hq = fma((double)(qv[c - j] + qv[c + j]), P.k[j], hq);
+            }
+            H[0][row][8 * g + o] = hx;
+            H[1][row][8 * g + o] = hy;
+            H[2][row][8 * g + o] = hp;
+            H[3][row][8 * g + o] = hq;
+        }
+    }
+    __syncthreads();
+    // ---- phase 3: column pass + SSIM formula, thread = (column, 7 consecutive rows) --------------------
+    double sum_int = 0.0, sum_all = 0.0;
+    {
+        const int col = tid & 31, rg = tid >> 5;
+        const int mx = bx0 + col;
+#pragma unroll 1
+        for (int r = 0; r < 7; ++r) {
+            const int orow = rg * 7 + r;
+            const int my = by0 + orow;
+            if (orow >= AG_TY || my >= P.ry1 || my >= P.h || mx >= P.w) break;
+            double u[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                double acc = H[m][orow + AG_R][col] * P.k[0];
+#pragma unroll
+                for (int j = 1; j <= AG_R; ++j)
+                    acc = fma(H[m][orow + AG_R - j][col] + H[m][orow + AG_R + j][col], P.k[j], acc);
+                u[m] = acc;
+            }
+            const double spq = 0.5 * (u[2] + u[3]), dpq = 0.25 * (u[2] - u[3]);
+            const bool interior = my >= AG_R && my < P.h - AG_R && mx >= AG_R && mx < P.w - AG_R;
+            if (P.same_c) {
+                const double sv = ssim_value(u[0], u[1], spq, dpq, P.c1a, P.c2a);
+                sum_all += sv;
+                if (interior) sum_int += sv;
+            } else {
+                if (P.flags & ASSESS_SIMPLE) sum_all += ssim_value(u[0], u[1], spq, dpq, P.c1b, P.c2b);
+                if (interior && (P.flags & ASSESS_GAUSS)) sum_int += ssim_value(u[0], u[1], spq, dpq, P.c1a, P.c2a);
+            }
+        }
+    }
+    // ---- phase 4: block reduction -> part[block][0..2] ---------------------------------------------------
+    sum_int = wave_sum_f64(sum_int);
+    sum_all = wave_sum_f64(sum_all);
+    double dsse = wave_sum_f64((double)sse);          // per-thread sums are < 2^40: exact in fp64
+    if ((tid & 63) == 0) {
+        red[tid >> 6][0] = sum_int;
+        red[tid >> 6][1] = sum_all;
+        red[tid >> 6][2] = dsse;
+    }
+    __syncthreads();
+    if (tid < 3) {
+        const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        part[blk * 3 + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+    }
+}
+
+#define AU_TX 64
+#define AU_TY 26
+#define AU_R 3
+#define AU_ROWS (AU_TY + 2 * AU_R) /* 32 */
+#define AU_COLS (AU_TX + 2 * AU_R) /* 70 */
+#define AU_GP 72
+
+template <int CN>
+__global__ __launch_bounds__(256) void k_assess_uniform(const unsigned char *__restrict__ a, long long sa,
+                                                        const unsigned char *__restrict__ b, long long sb,
+                                                        AssessParams P, double *__restrict__ part)
+{
+    __shared__ unsigned char gxs[AU_ROWS][AU_GP], gys[AU_ROWS][AU_GP];
+    __shared__ int4 HS[AU_ROWS][AU_TX + 1];
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    const int bx0 = blockIdx.x * AU_TX, by0 = P.ry0 + blockIdx.y * AU_TY;
+    for (int i = tid; i < AU_ROWS * AU_COLS; i += 256) {
+        const int ly = i / AU_COLS, lx = i - ly * AU_COLS;
+        const int sy = reflect101(by0 - AU_R + ly, P.h), sx = reflect101(bx0 - AU_R + lx, P.w);
+        int ga, gb;
+        unsigned sq;
+        load_gray_pair<CN>(a, sa, b, sb, sy, sx, P.shift, ga, gb, sq);
+        gxs[ly][lx] = (unsigned char)ga;
+        gys[ly][lx] = (unsigned char)gb;
+    }
+    __syncthreads();
+    {   // row pass: sliding 7-tap integer sums, thread = (row, 8 output columns)
+        const int row = tid >> 3, g = tid & 7;
+        int xv[14], yv[14], xx[14], yy[14], xy[14];
+#pragma unroll
+        for (int i = 0; i < 14; ++i) {
+            xv[i] = gxs[row][8 * g + i];
+            yv[i] = gys[row][8 * g + i];
+            // Opaque to the optimiser: with the values known to be zero-extended bytes, hipcc (ROCm 7.2) folds
+            // the sliding sums of products into v_perm_b32 + v_dot4_u32_u8 sequences that give wrong sums.
+            asm volatile("" : "+v"(xv[i]), "+v"(yv[i]));
+            xx[i] = xv[i] * xv[i];
+            yy[i] = yv[i] * yv[i];
+            xy[i] = xv[i] * yv[i];
+        }
+        int sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            sx += xv[i]; sy += yv[i];
+            sxx += xx[i]; syy += yy[i]; sxy += xy[i];
+        }
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            HS[row][8 * g + o] = make_int4(sx | (sy << 16), sxx, syy, sxy);
+            if (o < 7) {
+                sx = sx + xv[o + 7] - xv[o];
+                sy = sy + yv[o + 7] - yv[o];
+                sxx = sxx + xx[o + 7] - xx[o];
+                syy = syy + yy[o + 7] - yy[o];
+                sxy = sxy + xy[o + 7] - xy[o];
+            }
+        }
+    }
+    __syncthreads();
+    double sum = 0.0;
+    {   // column pass: sliding 7-row integer sums, thread = (column, 7 consecutive rows)
+        const int col = tid & 63, rg = tid >> 6;
+        const int mx = bx0 + col;
+        const int r_first = rg * 7;
+        int t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int4 v = HS[min(r_first + i, AU_ROWS - 1)][col];
+            t0 += v.x; t1 += v.y; t2 += v.z; t3 += v.w;
+        }
+        const double inv = 1.0 / 49.0, cn = 49.0 / 48.0;
+#pragma unroll 1
+        for (int r = 0; r < 7; ++r) {
+            const int orow = r_first + r;
+            const int my = by0 + orow;
+            if (orow >= AU_TY || my >= P.ry1) break;
+            if (my >= AU_R && my < P.h - AU_R && mx >= AU_R && mx < P.w - AU_R) {
+                const double ux = (double)(t0 & 0xFFFF) * inv, uy = (double)((unsigned)t0 >> 16) * inv;
+                const double uxx = (double)t1 * inv, uyy = (double)t2 * inv, uxy = (double)t3 * inv;
+                const double vx = cn * (uxx - ux * ux), vy = cn * (uyy - uy * uy), vxy = cn * (uxy - ux * uy);
+                const double a1 = 2.0 * ux * uy + P.c1a, a2 = 2.0 * vxy + P.c2a;
+                const double b1 = ux * ux + uy * uy + P.c1a, b2 = vx + vy + P.c2a;
+                sum += (a1 * a2) / (b1 * b2);
+            }
+            if (r < 6 && orow + 7 < AU_ROWS) {
+                const int4 vn = HS[orow + 7][col], vo = HS[orow][col];
+                t0 += vn.x - vo.x; t1 += vn.y - vo.y; t2 += vn.z - vo.z; t3 += vn.w - vo.w;
+            }
+        }
+    }
+    sum = wave_sum_f64(sum);
+    if ((tid & 63) == 0) red[tid >> 6] = sum;
+    __syncthreads();
+    if (tid == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+// Deterministic two-level sum of per-block partials laid out as part[i * ncomp + comp]:
+// level 1: block j sums entries [j*1024, (j+1)*1024) in a fixed tree -> tmp[j * ncomp + comp];
+// level 2 (one block): sums the level-1 results -> out[comp].
+__global__ __launch_bounds__(256) void k_reduce_partials(const double *__restrict__ part, long long n, int ncomp,
+                                                         double *__restrict__ out)
 {
     __shared__ double sh[256];
-    double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    const long long base = (long long)blockIdx.x * 1024;
+    for (int comp = 0; comp < ncomp; ++comp) {
+        double s = 0.0;
+        for (int k = 0; k < 4; ++k) {
+            const long long i = base + k * 256 + threadIdx.x;
+            if (i < n) s += part[i * ncomp + comp];
+        }
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[(size_t)blockIdx.x * ncomp + comp] = sh[0];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = sh[0];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1415,19 +1938,35 @@ static int blend_impl(sr_blend_plan *P, bool lap, int dtype, void *const *h_d_ti
     }
     {
         ProfScope ps(ctx, lap ? "final_gather" : "weighted_gather");
-        dim3 grid((P->canvas_w + 63) / 64, (rows + 3) / 4);
+        if (P->cn == 3 || P->cn == 1) {
+            dim3 grid((P->canvas_w + 255) / 256, (rows + 7) / 8);
+#define LAUNCH_BLK(DT, LAPV, CNV)                                                                               \
+    hipLaunchKernelGGL((k_final_blk<DT, LAPV, CNV>), grid, block, 0, ctx->stream, P->d_tiles, P->d_srcs, P->n,   \
+                       P->d_arena, P->d_luts, d_canvas, (long long)canvas_stride, d_canvas_f32, P->canvas_w,     \
+                       P->row_begin, P->row_end)
+            if (P->cn == 3) {
+                if (lap) { if (dtype == SR_U8) LAUNCH_BLK(SRC_U8, true, 3); else LAUNCH_BLK(SRC_F32, true, 3); }
+                else     { if (dtype == SR_U8) LAUNCH_BLK(SRC_U8, false, 3); else LAUNCH_BLK(SRC_F32, false, 3); }
+            } else {
+                if (lap) { if (dtype == SR_U8) LAUNCH_BLK(SRC_U8, true, 1); else LAUNCH_BLK(SRC_F32, true, 1); }
+                else     { if (dtype == SR_U8) LAUNCH_BLK(SRC_U8, false, 1); else LAUNCH_BLK(SRC_F32, false, 1); }
+            }
+#undef LAUNCH_BLK
+        } else {
+            dim3 grid((P->canvas_w + 63) / 64, (rows + 3) / 4);
 #define LAUNCH_FINAL(DT, LAPV)                                                                                  \
     hipLaunchKernelGGL((k_final<DT, LAPV>), grid, block, 0, ctx->stream, P->d_tiles, P->d_srcs, P->n, P->cn,     \
                        P->d_arena, P->d_luts, d_canvas, (long long)canvas_stride, d_canvas_f32, P->canvas_w,     \
                        P->row_begin, P->row_end)
-        if (lap) {
-            if (dtype == SR_U8) LAUNCH_FINAL(SRC_U8, true);
-            else LAUNCH_FINAL(SRC_F32, true);
-        } else {
-            if (dtype == SR_U8) LAUNCH_FINAL(SRC_U8, false);
-            else LAUNCH_FINAL(SRC_F32, false);
-        }
+            if (lap) {
+                if (dtype == SR_U8) LAUNCH_FINAL(SRC_U8, true);
+                else LAUNCH_FINAL(SRC_F32, true);
+            } else {
+                if (dtype == SR_U8) LAUNCH_FINAL(SRC_U8, false);
+                else LAUNCH_FINAL(SRC_F32, false);
+            }
 #undef LAUNCH_FINAL
+        }
     }
     return check_launch("final gather");
 }
@@ -1614,58 +2153,142 @@ int sr_sse_u8(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uint8_t *
     return SR_OK;
 }
 
-static int ssim_params(int h, int w, int cn, int mode, int gray_shift, double data_range, int row_begin, int row_end,
-                       SsimParams *P)
+// ---- fused assessment ---------------------------------------------------------------------------------------
+}  // extern "C"
+
+__global__ void k_assess_store(const double *__restrict__ g, const double *__restrict__ u, int flags,
+                               sr_assess_sums *__restrict__ out)
 {
-    if (h < 1 || w < 1 || (cn != 1 && cn != 3)) return sr_set_error(SR_ERR_INVALID_ARG, "sr_ssim_u8: need h,w >= 1 and 1 or 3 channels");
-    if (gray_shift != 14 && gray_shift != 15) return sr_set_error(SR_ERR_INVALID_ARG, "sr_ssim_u8: gray_shift must be 14 or 15");
-    memset(P, 0, sizeof(*P));
-    P->h = h;
-    P->w = w;
-    P->cn = cn;
-    P->shift = gray_shift;
-    int pad;
-    if (mode == SR_SSIM_UNIFORM7) {
-        P->klen = 7;
-        pad = 3;
-        P->cov_norm = 49.0 / 48.0;
-        P->bmode = PAD_REFLECT;
-        for (int i = 0; i < 7; ++i) P->k[i] = 1.0 / 7.0;
-    } else if (mode == SR_SSIM_GAUSS11 || mode == SR_SSIM_SIMPLE) {
-        P->klen = 11;
-        P->cov_norm = 1.0;
-        double s = 0;
-        if (mode == SR_SSIM_GAUSS11) {
-            pad = 5;
-            P->bmode = PAD_REFLECT;
-            for (int i = 0; i < 11; ++i) {
-                const double x = i - 5;
-                P->k[i] = std::exp(-0.5 / (1.5 * 1.5) * x * x);
-                s += P->k[i];
-            }
-        } else {
-            pad = 0;
-            P->bmode = PAD_MIRROR;
-            data_range = 255.0;
-            for (int i = 0; i < 11; ++i) {
-                const double x = i - 5.0;
-                P->k[i] = std::exp(-(x * x) / (2.0 * 1.5 * 1.5));
-                s += P->k[i];
-            }
-        }
-        for (int i = 0; i < 11; ++i) P->k[i] /= s;
-    } else {
-        return sr_set_error(SR_ERR_INVALID_ARG, "sr_ssim_u8: unknown mode %d", mode);
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    out->ssim_gauss = (g && (flags & ASSESS_GAUSS)) ? g[0] : 0.0;
+    out->ssim_simple = (g && (flags & ASSESS_SIMPLE)) ? g[1] : 0.0;
+    out->sse = (g && (flags & ASSESS_SSE)) ? g[2] : 0.0;
+    out->ssim_uniform = (u && (flags & ASSESS_UNIFORM)) ? u[0] : 0.0;
+}
+
+// reduce part[n][ncomp] -> returns pointer (inside the two ping-pong buffers) holding ncomp results
+static const double *reduce_partials(sr_ctx *ctx, const double *part, long long n, int ncomp, double *buf0, double *buf1)
+{
+    const double *src = part;
+    double *dst = buf0;
+    while (true) {
+        const long long nb = (n + 1023) / 1024;
+        hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)nb), dim3(256), 0, ctx->stream, src, n, ncomp, dst);
+        if (nb == 1) return dst;
+        src = dst;
+        dst = (dst == buf0) ? buf1 : buf0;
+        n = nb;
     }
-    P->rad = P->klen / 2;
+}
+
+extern "C" {
+
+static void gauss_taps(double *k6)
+{
+    double k[11], sum = 0.0;
+    for (int i = 0; i < 11; ++i) {
+        const double x = i - 5;
+        k[i] = std::exp(-0.5 / (1.5 * 1.5) * x * x);     // scipy.ndimage._gaussian_kernel1d(sigma=1.5, radius=5)
+        sum += k[i];
+    }
+    for (int j = 0; j <= 5; ++j) k6[j] = k[5 + j] / sum;
+}
+
+int sr_ssim_count(int h, int w, int mode, int row_begin, int row_end, uint64_t *count)
+{
+    if (!count || h < 1 || w < 1) return sr_set_error(SR_ERR_INVALID_ARG, "sr_ssim_count: bad arguments");
+    int pad;
+    if (mode == SR_SSIM_UNIFORM7) pad = 3;
+    else if (mode == SR_SSIM_GAUSS11) pad = 5;
+    else if (mode == SR_SSIM_SIMPLE) pad = 0;
+    else return sr_set_error(SR_ERR_INVALID_ARG, "sr_ssim_count: unknown mode %d", mode);
+    const long long y0 = std::max(pad, row_begin), y1 = std::min(h - pad, row_end), nx = (long long)w - 2 * pad;
+    *count = (y1 > y0 && nx > 0) ? (uint64_t)((y1 - y0) * nx) : 0;
+    return SR_OK;
+}
+
+int sr_assess_u8_async(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uint8_t *d_b, int64_t stride_b, int h,
+                       int w, int cn, int gray_shift, double data_range, int row_begin, int row_end, int flags,
+                       sr_assess_sums *d_out)
+{
+    CTX_ENTER(ctx);
+    if (!d_a || !d_b || !d_out) return sr_set_error(SR_ERR_INVALID_ARG, "sr_assess_u8: null argument");
+    if (h < 1 || w < 1 || (cn != 1 && cn != 3)) return sr_set_error(SR_ERR_INVALID_ARG, "sr_assess_u8: need h,w >= 1 and 1 or 3 channels");
+    if (gray_shift != 14 && gray_shift != 15) return sr_set_error(SR_ERR_INVALID_ARG, "sr_assess_u8: gray_shift must be 14 or 15");
+    if (stride_a < (int64_t)w * cn || stride_b < (int64_t)w * cn) return sr_set_error(SR_ERR_SHAPE, "sr_assess_u8: stride smaller than a row");
+    row_begin = std::max(row_begin, 0);
+    row_end = std::min(row_end, h);
+    AssessParams P;
+    memset(&P, 0, sizeof(P));
+    P.h = h; P.w = w; P.shift = gray_shift; P.ry0 = row_begin; P.ry1 = row_end; P.flags = flags;
+    P.c1a = (0.01 * data_range) * (0.01 * data_range);
+    P.c2a = (0.03 * data_range) * (0.03 * data_range);
+    P.c1b = (0.01 * 255.0) * (0.01 * 255.0);
+    P.c2b = (0.03 * 255.0) * (0.03 * 255.0);
+    P.same_c = (P.c1a == P.c1b && P.c2a == P.c2b) ? 1 : 0;
+    gauss_taps(P.k);
+    const int rows = row_end - row_begin;
+    const bool need_g = rows > 0 && (flags & (ASSESS_SSE | ASSESS_GAUSS | ASSESS_SIMPLE));
+    const bool need_u = rows > 0 && (flags & ASSESS_UNIFORM);
+    const long long gbx = (w + AG_TX - 1) / AG_TX, gby = (rows + AG_TY - 1) / AG_TY;
+    const long long ubx = (w + AU_TX - 1) / AU_TX, uby = (rows + AU_TY - 1) / AU_TY;
+    const size_t n_g = need_g ? (size_t)(gbx * gby) : 0, n_u = need_u ? (size_t)(ubx * uby) : 0;
+    const size_t red_doubles = ((std::max(n_g, n_u) + 1023) / 1024 + 1) * 3;
+    auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t o_part_g = 0, o_part_u = o_part_g + al(n_g * 3 * 8), o_r0 = o_part_u + al(n_u * 8),
+                 o_r1 = o_r0 + al(red_doubles * 8), o_r2 = o_r1 + al(red_doubles * 8), o_r3 = o_r2 + al(red_doubles * 8),
+                 total = o_r3 + al(red_doubles * 8);
+    void *scr = nullptr;
+    int rc = ctx_scratch(ctx, std::max<size_t>(total, (size_t)8 << 20), &scr);
+    if (rc) return rc;
+    char *base = (char *)scr;
+    const double *res_g = nullptr, *res_u = nullptr;
+    if (need_g) {
+        ProfScope ps(ctx, "assess_gauss_sse");
+        double *part = (double *)(base + o_part_g);
+        if (cn == 3) hipLaunchKernelGGL(k_assess_gauss<3>, dim3((unsigned)gbx, (unsigned)gby), dim3(256), 0, ctx->stream, d_a, (long long)stride_a, d_b, (long long)stride_b, P, part);
+        else hipLaunchKernelGGL(k_assess_gauss<1>, dim3((unsigned)gbx, (unsigned)gby), dim3(256), 0, ctx->stream, d_a, (long long)stride_a, d_b, (long long)stride_b, P, part);
+        res_g = reduce_partials(ctx, part, (long long)n_g, 3, (double *)(base + o_r0), (double *)(base + o_r1));
+    }
+    if (need_u) {
+        ProfScope ps(ctx, "assess_uniform");
+        double *part = (double *)(base + o_part_u);
+        if (cn == 3) hipLaunchKernelGGL(k_assess_uniform<3>, dim3((unsigned)ubx, (unsigned)uby), dim3(256), 0, ctx->stream, d_a, (long long)stride_a, d_b, (long long)stride_b, P, part);
+        else hipLaunchKernelGGL(k_assess_uniform<1>, dim3((unsigned)ubx, (unsigned)uby), dim3(256), 0, ctx->stream, d_a, (long long)stride_a, d_b, (long long)stride_b, P, part);
+        res_u = reduce_partials(ctx, part, (long long)n_u, 1, (double *)(base + o_r2), (double *)(base + o_r3));
+    }
+    hipLaunchKernelGGL(k_assess_store, dim3(1), dim3(64), 0, ctx->stream, res_g, res_u, flags, d_out);
+    return check_launch("assess");
+}
+
+int sr_assess_u8(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uint8_t *d_b, int64_t stride_b, int h, int w,
+                 int cn, int gray_shift, double data_range, int row_begin, int row_end, int flags, sr_assess_sums *h_out)
+{
+    CTX_ENTER(ctx);
+    if (!h_out) return sr_set_error(SR_ERR_INVALID_ARG, "sr_assess_u8: null result");
+    void *res = nullptr;
+    HIPCHK(hipMalloc(&res, sizeof(sr_assess_sums)));
+    int rc = sr_assess_u8_async(ctx, d_a, stride_a, d_b, stride_b, h, w, cn, gray_shift, data_range, row_begin, row_end,
+                                flags, (sr_assess_sums *)res);
+    if (rc == SR_OK) {
+        hipError_t e = hipMemcpyAsync(h_out, res, sizeof(sr_assess_sums), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = stream_sync(ctx);
+        if (e != hipSuccess) rc = sr_set_error(SR_ERR_HIP, "sr_assess_u8: D2H: %s", hipGetErrorString(e));
+    }
+    (void)stream_sync(ctx);
+    (void)hipFree(res);
+    return rc;
+}
+
+static int ssim_mode_check(int h, int w, int mode, int *flag, size_t *field_off)
+{
+    int pad;
+    if (mode == SR_SSIM_UNIFORM7) { pad = 3; *flag = ASSESS_UNIFORM; *field_off = offsetof(sr_assess_sums, ssim_uniform); }
+    else if (mode == SR_SSIM_GAUSS11) { pad = 5; *flag = ASSESS_GAUSS; *field_off = offsetof(sr_assess_sums, ssim_gauss); }
+    else if (mode == SR_SSIM_SIMPLE) { pad = 0; *flag = ASSESS_SIMPLE; *field_off = offsetof(sr_assess_sums, ssim_simple); }
+    else return sr_set_error(SR_ERR_INVALID_ARG, "sr_ssim_u8: unknown mode %d", mode);
     if (h <= 2 * pad || w <= 2 * pad)
-        return sr_set_error(SR_ERR_SHAPE, "sr_ssim_u8: image %dx%d smaller than the %d-tap window", w, h, P->klen);
-    P->c1 = (0.01 * data_range) * (0.01 * data_range);
-    P->c2 = (0.03 * data_range) * (0.03 * data_range);
-    P->vy0 = std::max(pad, row_begin);
-    P->vy1 = std::min(h - pad, row_end);
-    P->vx0 = pad;
-    P->vx1 = w - pad;
+        return sr_set_error(SR_ERR_SHAPE, "sr_ssim_u8: image %dx%d smaller than the %d-tap window", w, h, 2 * pad + 1);
     return SR_OK;
 }
 
@@ -1675,27 +2298,22 @@ int sr_ssim_u8_async(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const ui
 {
     CTX_ENTER(ctx);
     if (!d_a || !d_b || !d_sum || !h_count) return sr_set_error(SR_ERR_INVALID_ARG, "sr_ssim_u8: null argument");
-    SsimParams P;
-    int rc = ssim_params(h, w, cn, mode, gray_shift, data_range, row_begin, row_end, &P);
+    int flag = 0;
+    size_t off = 0;
+    int rc = ssim_mode_check(h, w, mode, &flag, &off);
     if (rc) return rc;
-    HIPCHK(hipMemsetAsync(d_sum, 0, sizeof(double), ctx->stream));
-    if (P.vy0 >= P.vy1) {
-        *h_count = 0;
-        return SR_OK;
-    }
-    *h_count = (uint64_t)(P.vy1 - P.vy0) * (uint64_t)(P.vx1 - P.vx0);
-    const int gx = (P.vx1 - P.vx0 + SS_TX - 1) / SS_TX, gy = (P.vy1 - P.vy0 + SS_TY - 1) / SS_TY;
+    rc = sr_ssim_count(h, w, mode, row_begin, row_end, h_count);
+    if (rc) return rc;
     void *scr = nullptr;
-    rc = ctx_scratch(ctx, sizeof(double) * (size_t)gx * gy + 64, &scr);
+    rc = ctx_scratch(ctx, (size_t)8 << 20, &scr);
     if (rc) return rc;
-    double *partials = (double *)((char *)scr + 64);
-    {
-        ProfScope ps(ctx, mode == SR_SSIM_UNIFORM7 ? "ssim_uniform7" : (mode == SR_SSIM_GAUSS11 ? "ssim_gauss11" : "ssim_simple"));
-        hipLaunchKernelGGL(k_ssim, dim3(gx, gy), dim3(256), 0, ctx->stream, d_a, (long long)stride_a, d_b,
-                           (long long)stride_b, P, partials);
-        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, (const double *)partials, gx * gy, d_sum);
-    }
-    return check_launch("ssim");
+    // the result record lives in the last 256 bytes of the (>= 8 MiB) scratch, clear of the partial buffers
+    sr_assess_sums *rec = (sr_assess_sums *)((char *)ctx->scratch + ctx->scratch_bytes - 256);
+    rc = sr_assess_u8_async(ctx, d_a, stride_a, d_b, stride_b, h, w, cn, gray_shift, data_range, row_begin, row_end, flag, rec);
+    if (rc) return rc;
+    rec = (sr_assess_sums *)((char *)ctx->scratch + ctx->scratch_bytes - 256);    // scratch may have grown
+    HIPCHK(hipMemcpyAsync(d_sum, (const char *)rec + off, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return SR_OK;
 }
 
 int sr_ssim_u8(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uint8_t *d_b, int64_t stride_b, int h, int w,
@@ -1704,18 +2322,17 @@ int sr_ssim_u8(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uint8_t 
 {
     CTX_ENTER(ctx);
     if (!h_sum || !h_count) return sr_set_error(SR_ERR_INVALID_ARG, "sr_ssim_u8: null result");
-    void *res = nullptr;
-    HIPCHK(hipMalloc(&res, 64));
-    int rc = sr_ssim_u8_async(ctx, d_a, stride_a, d_b, stride_b, h, w, cn, mode, gray_shift, data_range, row_begin,
-                              row_end, (double *)res, h_count);
-    if (rc == SR_OK) {
-        hipError_t e = hipMemcpyAsync(h_sum, res, sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) rc = sr_set_error(SR_ERR_HIP, "sr_ssim_u8: D2H: %s", hipGetErrorString(e));
-    }
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(res);
-    return rc;
+    int flag = 0;
+    size_t off = 0;
+    int rc = ssim_mode_check(h, w, mode, &flag, &off);
+    if (rc) return rc;
+    rc = sr_ssim_count(h, w, mode, row_begin, row_end, h_count);
+    if (rc) return rc;
+    sr_assess_sums sums;
+    rc = sr_assess_u8(ctx, d_a, stride_a, d_b, stride_b, h, w, cn, gray_shift, data_range, row_begin, row_end, flag, &sums);
+    if (rc) return rc;
+    *h_sum = *(const double *)((const char *)&sums + off);
+    return SR_OK;
 }
 
 int sr_rgb2gray_u8(sr_ctx *ctx, const uint8_t *d_rgb, int64_t stride, int h, int w, int gray_shift, uint8_t *d_gray,

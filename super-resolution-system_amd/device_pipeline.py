@@ -4,7 +4,7 @@ This is the data-parallel form of the reference's stages 1/3/4 (main.py:293-379)
 on the GPU that owns them, the canvas is partitioned into horizontal strips (one per rank), every
 strip owner receives the tile rows (plus pyramid halo) it needs over RCCL / xGMI and blends its rows
 with exactly the kernels of the single-GPU path, so its rows are bit-identical to a 1-GPU run
-(SURVEY.md 8(e)).  Quality metrics are partial sums per strip + one 5-element all-reduce.
+(SURVEY.md 8(e)).  Quality metrics are partial sums per strip + one 4-element all-reduce.
 
 torch is used for what it is good at here: device buffers, the current stream and
 torch.distributed (backend "nccl" == RCCL on ROCm; "gloo" for the CPU rehearsal in tests/).
@@ -176,8 +176,7 @@ class DevicePipeline:
         self.recv_bufs = {t: torch.empty((b - a, geo.rects[t][2] * cn), **u8)
                           for (_, t, a, b) in self.xplan.recvs(rank)}
         self.canvas = torch.zeros((geo.canvas_h, geo.canvas_w * cn), **u8)
-        self.results = torch.zeros(5, dtype=torch.float64, device=self.dev)
-        self._sse_word = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self.results = torch.zeros(4, dtype=torch.float64, device=self.dev)   # sr_assess_sums
         self.plan = _native.BlendPlan(self.ctx, geo.rects, cn, geo.canvas_h, geo.canvas_w, geo.levels,
                                       geo.weight_type, self.row_begin, self.row_end)
         # per-tile (virtual) base pointers and strides for the blend
@@ -192,7 +191,6 @@ class DevicePipeline:
             else:
                 self._ptrs.append(self.recv_bufs[t].data_ptr() - a * stride)   # virtual row 0
             self._strides.append(stride)
-        self._ssim_counts = {}
 
     # -- stages ---------------------------------------------------------------------------------
     def stage_tile(self, image):
@@ -215,23 +213,19 @@ class DevicePipeline:
         self.plan.blend(self._ptrs, self._strides, self.canvas.data_ptr(), self.canvas.stride(0))
 
     def stage_assess(self, reference):
-        """PSNR (exact integer SSE) and the SSIM modes over this rank's strip, left on the device."""
+        """PSNR (exact integer SSE) and the three SSIM variants over this rank's strip, as partial sums left on
+        the device: one fused fp64 pass (SSE + Gaussian cropped + Gaussian full-frame) and one integer pass
+        (uniform 7x7) -- sr_assess_u8_async."""
         g = self.geo
         s0, s1 = self.strip
-        rowlen = g.canvas_w * g.cn
-        res = self.results
-        off = s0 * rowlen
-        self.ctx.sse_u8_async(reference.data_ptr() + s0 * reference.stride(0), reference.stride(0),
-                              self.canvas.data_ptr() + off, self.canvas.stride(0), s1 - s0, rowlen,
-                              self._sse_word.data_ptr())
-        res[0] = self._sse_word[0].to(self.torch.float64)
-        for i, mode in enumerate(("uniform", "gauss", "simple")):
-            if mode not in self.ssim_modes:
-                continue
-            n = self.ctx.ssim_u8_async(reference.data_ptr(), reference.stride(0), self.canvas.data_ptr(),
-                                       self.canvas.stride(0), g.canvas_h, g.canvas_w, g.cn, mode,
-                                       res.data_ptr() + 8 * (1 + i), row_begin=s0, row_end=s1)
-            self._ssim_counts[mode] = n
+        flags = _native.ASSESS_SSE
+        for mode, bit in (("uniform", _native.ASSESS_UNIFORM7), ("gauss", _native.ASSESS_GAUSS11),
+                          ("simple", _native.ASSESS_SIMPLE)):
+            if mode in self.ssim_modes:
+                flags |= bit
+        self.ctx.assess_u8_async(reference.data_ptr(), reference.stride(0), self.canvas.data_ptr(),
+                                 self.canvas.stride(0), g.canvas_h, g.canvas_w, g.cn, self.results.data_ptr(),
+                                 flags=flags, row_begin=s0, row_end=s1)
 
     def stage_reduce(self):
         if self.world > 1:
@@ -251,11 +245,9 @@ class DevicePipeline:
         g = self.geo
         vals = self.results.cpu().numpy()
         out = {"psnr": _native.psnr_from_sse(int(round(vals[0])), g.canvas_h * g.canvas_w * g.cn, 255.0)}
-        pads = {"uniform": 3, "gauss": 5, "simple": 0}
         for i, mode in enumerate(("uniform", "gauss", "simple")):
             if mode in self.ssim_modes:
-                cnt = (g.canvas_h - 2 * pads[mode]) * (g.canvas_w - 2 * pads[mode])
-                out[f"ssim_{mode}"] = float(vals[1 + i] / cnt)
+                out[f"ssim_{mode}"] = float(vals[1 + i] / _native.ssim_count(g.canvas_h, g.canvas_w, mode))
         return out
 
     def close(self):
