@@ -246,22 +246,21 @@ struct TileSrc {
 enum { SRC_U8 = 0, SRC_F32 = 1, SRC_PLANAR = 2, SRC_LUT = 3 };
 
 // Source accessors for the pyrDown kernel -----------------------------------------------------
-template <int SRC>
-struct SrcRow;  // row(r) then at(x, c)
+struct __attribute__((packed, aligned(4))) F4A {   // 4 floats at any float-aligned address
+    float v[4];
+};
+struct __attribute__((packed, aligned(16))) F4V {  // 4 floats at a 16-byte aligned address
+    float v[4];
+};
+struct __attribute__((packed, aligned(1))) U96 {   // 12 bytes at any address
+    unsigned a, b, c;
+};
 
-// level i -> i+1 of every tile (or weight class) in one launch.  One thread = one output pixel,
-// all planes.  Rows limited to the G window of the destination level.
+// One output pixel (all planes) of level lvl+1 from level lvl -- the generic form with every border rule.
 template <int SRC>
-__global__ __launch_bounds__(256) void k_down(const TileDev *__restrict__ tiles, const TileSrc *__restrict__ srcs,
-                                              int lvl, int cn, float *__restrict__ arena,
-                                              const float *__restrict__ luts)
+__device__ __forceinline__ void down_pixel(const TileDev &T, const TileSrc S, int lvl, int cn, int x, int y,
+                                           float *__restrict__ arena, const float *__restrict__ luts)
 {
-    const TileDev &T = tiles[blockIdx.z];
-    if (lvl + 1 >= T.nl) return;
-    const int wo = T.W[lvl + 1];
-    const int x = blockIdx.x * 64 + threadIdx.x;
-    const int y = T.g0[lvl + 1] + blockIdx.y * 4 + threadIdx.y;
-    if (x >= wo || y >= T.g1[lvl + 1]) return;
     const int hs = T.H[lvl], ws = T.W[lvl];
     int xi[5], yi[5];
 #pragma unroll
@@ -278,11 +277,11 @@ __global__ __launch_bounds__(256) void k_down(const TileDev *__restrict__ tiles,
         for (int k = 0; k < 5; ++k) {
             float s[5];
             if (SRC == SRC_U8) {
-                const unsigned char *r = (const unsigned char *)srcs[blockIdx.z].p + (size_t)yi[k] * srcs[blockIdx.z].stride;
+                const unsigned char *r = (const unsigned char *)S.p + (size_t)yi[k] * S.stride;
 #pragma unroll
                 for (int j = 0; j < 5; ++j) s[j] = (float)r[xi[j] * cn + c];
             } else if (SRC == SRC_F32) {
-                const float *r = (const float *)((const char *)srcs[blockIdx.z].p + (size_t)yi[k] * srcs[blockIdx.z].stride);
+                const float *r = (const float *)((const char *)S.p + (size_t)yi[k] * S.stride);
 #pragma unroll
                 for (int j = 0; j < 5; ++j) s[j] = r[xi[j] * cn + c];
             } else if (SRC == SRC_PLANAR) {
@@ -302,6 +301,129 @@ __global__ __launch_bounds__(256) void k_down(const TileDev *__restrict__ tiles,
         }
         const float v = ((rowv[2] * 6.0f + (rowv[1] + rowv[3]) * 4.0f) + rowv[0]) + rowv[4];
         dst[c * dplane] = v * (1.0f / 256.0f);
+    }
+}
+
+// level i -> i+1 of every tile (or weight class) in one launch.  One thread = one output pixel,
+// all planes.  Rows limited to the G window of the destination level.  (Generic kernel: weight classes,
+// fp32 HWC tiles, channel counts other than 1 / 3.)
+template <int SRC>
+__global__ __launch_bounds__(256) void k_down(const TileDev *__restrict__ tiles, const TileSrc *__restrict__ srcs,
+                                              int lvl, int cn, float *__restrict__ arena,
+                                              const float *__restrict__ luts)
+{
+    const TileDev &T = tiles[blockIdx.z];
+    if (lvl + 1 >= T.nl) return;
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = T.g0[lvl + 1] + blockIdx.y * 4 + threadIdx.y;
+    if (x >= T.W[lvl + 1] || y >= T.g1[lvl + 1]) return;
+    TileSrc S;
+    S.p = nullptr;
+    S.stride = 0;
+    if (SRC == SRC_U8 || SRC == SRC_F32) S = srcs[blockIdx.z];
+    down_pixel<SRC>(T, S, lvl, cn, x, y, arena, luts);
+}
+
+// Register-blocked pyrDown: one thread = 4 x 2 outputs of every plane.  The 7 x 11 input window is read
+// once per plane with vector loads (u8: three byte-aligned 12-byte loads per row for all channels;
+// planar fp32: float2 + float4 + float4 + float), the row pass is evaluated once per input row and
+// shared by the two output rows.  Threads whose window touches a border use down_pixel per output.
+struct __attribute__((packed, aligned(8))) F2A {
+    float v[2];
+};
+
+template <int SRC, int CN>
+__global__ __launch_bounds__(256) void k_down_blk(const TileDev *__restrict__ tiles, const TileSrc *__restrict__ srcs,
+                                                  int lvl, float *__restrict__ arena, const float *__restrict__ luts)
+{
+    const TileDev &T = tiles[blockIdx.z];
+    if (lvl + 1 >= T.nl) return;
+    const int wo = T.W[lvl + 1];
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y0 = T.g0[lvl + 1] + (blockIdx.y * 4 + threadIdx.y) * 2;
+    if (x0 >= wo || y0 >= T.g1[lvl + 1]) return;
+    const int nx = min(4, wo - x0), ny = min(2, T.g1[lvl + 1] - y0);
+    const int hs = T.H[lvl], ws = T.W[lvl];
+    TileSrc S;
+    S.p = nullptr;
+    S.stride = 0;
+    if (SRC == SRC_U8) S = srcs[blockIdx.z];
+    const bool interior = nx == 4 && 2 * x0 - 2 >= 0 && 2 * x0 + 9 <= ws - 1 && 2 * y0 - 2 >= 0 && 2 * y0 + 4 <= hs - 1;
+    if (!interior) {
+        for (int j = 0; j < ny; ++j)
+            for (int k = 0; k < nx; ++k) down_pixel<SRC>(T, S, lvl, CN, x0 + k, y0 + j, arena, luts);
+        return;
+    }
+    const int po = T.P[lvl + 1];
+    const size_t dplane = (size_t)T.H[lvl + 1] * po;
+    float *dst = arena + T.g_off[lvl + 1] + (size_t)y0 * po + x0;
+    if (SRC == SRC_U8) {
+        float hrow[7][CN][4];
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            // rows 5, 6 feed only the second output row; with ny == 1 they may lie outside the rows a strip owner
+            // holds of this tile (virtual base pointer), so they must not be touched
+            const int rr = (r >= 5 && ny < 2) ? 4 : r;
+            const unsigned char *row = (const unsigned char *)S.p + (size_t)(2 * y0 - 2 + rr) * S.stride + (size_t)(2 * x0 - 2) * CN;
+            float s[11][CN];
+            if (CN == 3) {
+                const U96 q0 = *(const U96 *)row, q1 = *(const U96 *)(row + 12), q2 = *(const U96 *)(row + 24);
+                const unsigned wds[9] = {q0.a, q0.b, q0.c, q1.a, q1.b, q1.c, q2.a, q2.b, q2.c};
+#pragma unroll
+                for (int b = 0; b < 33; ++b) s[b / 3][b % 3] = (float)((wds[b >> 2] >> (8 * (b & 3))) & 0xFFu);
+            } else {
+                const U96 q0 = *(const U96 *)row;
+                const unsigned wds[3] = {q0.a, q0.b, q0.c};
+#pragma unroll
+                for (int b = 0; b < 11; ++b) s[b][0] = (float)((wds[b >> 2] >> (8 * (b & 3))) & 0xFFu);
+            }
+#pragma unroll
+            for (int c = 0; c < CN; ++c)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    hrow[r][c][k] = ((s[2 * k + 2][c] * 6.0f + (s[2 * k + 1][c] + s[2 * k + 3][c]) * 4.0f) + s[2 * k][c]) + s[2 * k + 4][c];
+        }
+#pragma unroll
+        for (int c = 0; c < CN; ++c)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (j >= ny) break;
+                F4V o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float v = ((hrow[2 * j + 2][c][k] * 6.0f + (hrow[2 * j + 1][c][k] + hrow[2 * j + 3][c][k]) * 4.0f) + hrow[2 * j][c][k]) + hrow[2 * j + 4][c][k];
+                    o.v[k] = v * (1.0f / 256.0f);
+                }
+                *(F4V *)(dst + c * dplane + (size_t)j * po) = o;
+            }
+    } else {  // SRC_PLANAR
+        const int ps = T.P[lvl];
+        const size_t splane = (size_t)hs * ps;
+#pragma unroll 1
+        for (int c = 0; c < CN; ++c) {
+            float hrow[7][4];
+#pragma unroll
+            for (int r = 0; r < 7; ++r) {
+                const float *row = arena + T.g_off[lvl] + c * splane + (size_t)(2 * y0 - 2 + r) * ps + (2 * x0 - 2);
+                const F2A a = *(const F2A *)row;
+                const F4V b = *(const F4V *)(row + 2), d = *(const F4V *)(row + 6);
+                const float s[11] = {a.v[0], a.v[1], b.v[0], b.v[1], b.v[2], b.v[3], d.v[0], d.v[1], d.v[2], d.v[3], row[10]};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    hrow[r][k] = ((s[2 * k + 2] * 6.0f + (s[2 * k + 1] + s[2 * k + 3]) * 4.0f) + s[2 * k]) + s[2 * k + 4];
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (j >= ny) break;
+                F4V o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float v = ((hrow[2 * j + 2][k] * 6.0f + (hrow[2 * j + 1][k] + hrow[2 * j + 3][k]) * 4.0f) + hrow[2 * j][k]) + hrow[2 * j + 4][k];
+                    o.v[k] = v * (1.0f / 256.0f);
+                }
+                *(F4V *)(dst + c * dplane + (size_t)j * po) = o;
+            }
+        }
     }
 }
 
@@ -465,12 +587,6 @@ __device__ __forceinline__ void up_block(const float *__restrict__ plane, int hs
     up_cols2<YO>(h, r0, u);
 }
 
-struct __attribute__((packed, aligned(4))) F4A {
-    float v[4];
-};
-struct __attribute__((packed, aligned(1))) U96 {
-    unsigned a, b, c;
-};
 
 // interior form of up_block: every pixel of the thread is away from the level-1 borders, so the
 // border selects of up_h / the row clamps vanish; same expressions as the generic path otherwise
@@ -607,6 +723,84 @@ __device__ __forceinline__ void gather_tile(const TileDev &T, const TileSrc S, c
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (valid & (1u << (j * 4 + k))) wacc[j][k] += w0[j][k];
+}
+
+// R_i for one level of every tile, register-blocked: one thread = 4 x 2 pixels of level i, all planes.
+// Tile-local x0 is a multiple of 4 (so the pyrUp column phase is fixed: XO = false); the row phase follows
+// the parity of the row-window start and is uniform per tile.  Same expressions as k_up_level.
+template <int CN, bool YO>
+__device__ __forceinline__ void up_level_thread(const TileDev &T, int lvl, float *__restrict__ arena, int x0, int y0,
+                                                int ny)
+{
+    const int w = T.W[lvl], h = T.H[lvl], p = T.P[lvl];
+    const size_t plane = (size_t)h * p;
+    const int hs = T.H[lvl + 1], ws = T.W[lvl + 1], ps = T.P[lvl + 1];
+    const size_t splane = (size_t)hs * ps;
+    const int r0 = (y0 - 1) >> 1, c0 = (x0 - 1) >> 1;
+    const bool interior = c0 >= 0 && c0 + 3 <= ws - 1 && r0 >= 0 && r0 + 2 <= hs - 1;
+    const float *wrow = arena + T.w_off[lvl] + (size_t)y0 * p + x0;
+    F4V wv[2];
+    wv[0] = *(const F4V *)wrow;
+    wv[1] = (ny > 1) ? *(const F4V *)(wrow + p) : wv[0];
+#pragma unroll
+    for (int c = 0; c < CN; ++c) {
+        const float *g = arena + T.g_off[lvl] + c * plane + (size_t)y0 * p + x0;
+        float *r = arena + T.r_off[lvl] + c * plane + (size_t)y0 * p + x0;
+        F4V gv[2];
+        gv[0] = *(const F4V *)g;
+        gv[1] = (ny > 1) ? *(const F4V *)(g + p) : gv[0];
+        float ug[2][4], ur[2][4];
+        const float *gs = arena + T.g_off[lvl + 1] + c * splane;
+        const float *rs = arena + T.r_off[lvl + 1] + c * splane;
+        if (interior) {
+            up_block_interior<false, YO>(gs, ps, r0, c0, ug);
+            up_block_interior<false, YO>(rs, ps, r0, c0, ur);
+        } else {
+            up_block<false, YO>(gs, hs, ws, ps, r0, c0, ug);
+            up_block<false, YO>(rs, hs, ws, ps, r0, c0, ur);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (j >= ny) break;
+            F4V o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float lap = gv[j].v[k] - ug[j][k];
+                const float wl = lap * wv[j].v[k];
+                o.v[k] = ur[j][k] + wl;
+            }
+            *(F4V *)(r + (size_t)j * p) = o;      // columns >= w land in the row padding (pitch is a multiple of 16)
+        }
+    }
+}
+
+template <int CN>
+__global__ __launch_bounds__(256) void k_up_level_blk(const TileDev *__restrict__ tiles, int lvl, float *__restrict__ arena)
+{
+    const TileDev &T = tiles[blockIdx.z];
+    if (lvl >= T.nl) return;
+    const int w = T.W[lvl], h = T.H[lvl], p = T.P[lvl];
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y0 = T.r0[lvl] + (blockIdx.y * 4 + threadIdx.y) * 2;
+    if (x0 >= w || y0 >= T.r1[lvl]) return;
+    const int ny = min(2, T.r1[lvl] - y0);
+    if (lvl == T.nl - 1) {
+        const size_t plane = (size_t)h * p;
+        for (int j = 0; j < ny; ++j) {
+            const F4V wv = *(const F4V *)(arena + T.w_off[lvl] + (size_t)(y0 + j) * p + x0);
+#pragma unroll
+            for (int c = 0; c < CN; ++c) {
+                const F4V gv = *(const F4V *)(arena + T.g_off[lvl] + c * plane + (size_t)(y0 + j) * p + x0);
+                F4V o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o.v[k] = gv.v[k] * wv.v[k];
+                *(F4V *)(arena + T.r_off[lvl] + c * plane + (size_t)(y0 + j) * p + x0) = o;
+            }
+        }
+        return;
+    }
+    if (y0 & 1) up_level_thread<CN, true>(T, lvl, arena, x0, y0, ny);
+    else up_level_thread<CN, false>(T, lvl, arena, x0, y0, ny);
 }
 
 #define FINAL_MAX_CAND 64
@@ -787,20 +981,45 @@ struct ExtractDesc {
     int out_w, out_h;
 };
 
+struct __attribute__((packed, aligned(1))) U128U {
+    unsigned a, b, c, d;
+};
+struct __attribute__((packed, aligned(4))) U128A {
+    unsigned a, b, c, d;
+};
+
+// One thread = 16 consecutive bytes of one output row.  Inside the source rectangle that is a straight
+// copy: one byte-aligned 16-byte load (the source offset x*cn is arbitrary) and one dword-aligned store;
+// bytes in the padded band (and ragged tails) take the per-byte border rule.
 __global__ __launch_bounds__(256) void k_tile_extract(const unsigned char *__restrict__ img, long long istride,
                                                       int cn, const ExtractDesc *__restrict__ descs, int pad_mode)
 {
     const ExtractDesc D = descs[blockIdx.z];
-    const int c = blockIdx.x * 64 + threadIdx.x, r = blockIdx.y * 4 + threadIdx.y;
-    if (c >= D.out_w || r >= D.out_h) return;
-    unsigned char *d = D.dst + (size_t)r * D.dstride + (size_t)c * cn;
-    if (pad_mode == PAD_CONSTANT && (r >= D.h || c >= D.w)) {
-        for (int k = 0; k < cn; ++k) d[k] = 0;
+    const int r = blockIdx.y * 4 + threadIdx.y;
+    const long long b0 = ((long long)blockIdx.x * 64 + threadIdx.x) * 16;
+    const long long row_bytes = (long long)D.out_w * cn;
+    if (r >= D.out_h || b0 >= row_bytes) return;
+    unsigned char *d = D.dst + (size_t)r * D.dstride + b0;
+    const bool dst_al = ((((size_t)D.dst) | (size_t)D.dstride) & 3) == 0;
+    if (r < D.h && b0 + 16 <= (long long)D.w * cn && dst_al) {
+        const unsigned char *sp = img + (size_t)(D.y + r) * istride + (size_t)D.x * cn + b0;
+        const U128U v = *(const U128U *)sp;
+        U128A o;
+        o.a = v.a; o.b = v.b; o.c = v.c; o.d = v.d;
+        *(U128A *)d = o;
         return;
     }
-    const int sr = border_index(r, D.h, pad_mode), sc = border_index(c, D.w, pad_mode);
-    const unsigned char *s = img + (size_t)(D.y + sr) * istride + (size_t)(D.x + sc) * cn;
-    for (int k = 0; k < cn; ++k) d[k] = s[k];
+    const int nb = (int)min((long long)16, row_bytes - b0);
+    for (int i = 0; i < nb; ++i) {
+        const long long bb = b0 + i;
+        const int c = (int)(bb / cn), k = (int)(bb - (long long)c * cn);
+        if (pad_mode == PAD_CONSTANT && (r >= D.h || c >= D.w)) {
+            d[i] = 0;
+            continue;
+        }
+        const int sr = border_index(r, D.h, pad_mode), sc = border_index(c, D.w, pad_mode);
+        d[i] = img[(size_t)(D.y + sr) * istride + (size_t)(D.x + sc) * cn + k];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1577,7 +1796,8 @@ static int extract_impl(sr_ctx *ctx, const uint8_t *d_img, int img_h, int img_w,
     HIPCHK(upload_small(ctx, scr, descs.data(), sizeof(ExtractDesc) * n));
     {
         ProfScope ps(ctx, name);
-        dim3 grid((mw + 63) / 64, (mh + 3) / 4, n), block(64, 4);
+        const long long chunks = ((long long)mw * cn + 15) / 16;
+        dim3 grid((unsigned)((chunks + 63) / 64), (mh + 3) / 4, n), block(64, 4);
         hipLaunchKernelGGL(k_tile_extract, grid, block, 0, ctx->stream, d_img, (long long)img_stride, cn,
                            (const ExtractDesc *)scr, pad_mode);
     }
@@ -1916,6 +2136,18 @@ static int blend_impl(sr_blend_plan *P, bool lap, int dtype, void *const *h_d_ti
         for (int i = 0; i + 1 < P->max_nl; ++i) {
             if (P->max_grows[i + 1] <= 0) continue;
             ProfScope ps(ctx, i == 0 ? "down_l0" : "down_l1p");
+            const bool blk = (P->cn == 3 || P->cn == 1) && !(i == 0 && dtype != SR_U8);
+            if (blk) {
+                dim3 grid((P->max_w[i + 1] + 255) / 256, (P->max_grows[i + 1] + 7) / 8, P->n);
+                if (i == 0) {
+                    if (P->cn == 3) hipLaunchKernelGGL((k_down_blk<SRC_U8, 3>), grid, block, 0, ctx->stream, P->d_tiles, P->d_srcs, i, P->d_arena, P->d_luts);
+                    else hipLaunchKernelGGL((k_down_blk<SRC_U8, 1>), grid, block, 0, ctx->stream, P->d_tiles, P->d_srcs, i, P->d_arena, P->d_luts);
+                } else {
+                    if (P->cn == 3) hipLaunchKernelGGL((k_down_blk<SRC_PLANAR, 3>), grid, block, 0, ctx->stream, P->d_tiles, P->d_srcs, i, P->d_arena, P->d_luts);
+                    else hipLaunchKernelGGL((k_down_blk<SRC_PLANAR, 1>), grid, block, 0, ctx->stream, P->d_tiles, P->d_srcs, i, P->d_arena, P->d_luts);
+                }
+                continue;
+            }
             dim3 grid((P->max_w[i + 1] + 63) / 64, (P->max_grows[i + 1] + 3) / 4, P->n);
             if (i == 0) {
                 if (dtype == SR_U8) hipLaunchKernelGGL(k_down<SRC_U8>, grid, block, 0, ctx->stream, P->d_tiles, P->d_srcs, i, P->cn, P->d_arena, P->d_luts);
@@ -1930,8 +2162,14 @@ static int blend_impl(sr_blend_plan *P, bool lap, int dtype, void *const *h_d_ti
         for (int i = P->max_nl - 1; i >= 1; --i) {
             if (P->max_rrows[i] <= 0) continue;
             ProfScope ps(ctx, "up_level");
-            dim3 grid((P->max_w[i] + 63) / 64, (P->max_rrows[i] + 3) / 4, P->n);
-            hipLaunchKernelGGL(k_up_level, grid, block, 0, ctx->stream, P->d_tiles, i, P->cn, P->d_arena);
+            if (P->cn == 3 || P->cn == 1) {
+                dim3 grid((P->max_w[i] + 255) / 256, (P->max_rrows[i] + 7) / 8, P->n);
+                if (P->cn == 3) hipLaunchKernelGGL(k_up_level_blk<3>, grid, block, 0, ctx->stream, P->d_tiles, i, P->d_arena);
+                else hipLaunchKernelGGL(k_up_level_blk<1>, grid, block, 0, ctx->stream, P->d_tiles, i, P->d_arena);
+            } else {
+                dim3 grid((P->max_w[i] + 63) / 64, (P->max_rrows[i] + 3) / 4, P->n);
+                hipLaunchKernelGGL(k_up_level, grid, block, 0, ctx->stream, P->d_tiles, i, P->cn, P->d_arena);
+            }
         }
         rc = check_launch("up chain");
         if (rc) return rc;
