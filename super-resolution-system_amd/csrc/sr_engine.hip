@@ -1171,13 +1171,92 @@ __device__ __forceinline__ void load_gray_pair(const unsigned char *__restrict__
     }
 }
 
+struct __attribute__((packed, aligned(1))) U32U {
+    unsigned a;
+};
+
+__device__ __forceinline__ int gray_rgb(int r, int g, int b, int shift)
+{
+    return shift == 15 ? (r * 9798 + g * 19235 + b * 3735 + (1 << 14)) >> 15
+                       : (r * 4899 + g * 9617 + b * 1868 + (1 << 13)) >> 14;
+}
+
+// Gray halo tile of both images into LDS, four pixels per thread step (one 12-byte load per image for RGB,
+// one 4-byte load for gray input); groups that leave the image take the per-pixel REFLECT_101 path.
+// Returns this thread's share of the squared differences of the block's interior pixels.
+template <int CN, int ROWS, int COLS4, int GP, int R, int TX, int TY>
+__device__ __forceinline__ unsigned long long load_gray_tile(const unsigned char *__restrict__ a, long long sa,
+                                                             const unsigned char *__restrict__ b, long long sb,
+                                                             int h, int w, int shift, int ry1, bool want_sse, int bx0,
+                                                             int by0, unsigned char (*gxs)[GP], unsigned char (*gys)[GP])
+{
+    unsigned long long sse = 0;
+    for (int i = threadIdx.x; i < ROWS * COLS4; i += 256) {
+        const int ly = i / COLS4, lx = (i - ly * COLS4) * 4;
+        const int gy = by0 - R + ly, gx = bx0 - R + lx;
+        const int sy = reflect101(gy, h);
+        int ga[4], gb[4];
+        unsigned sq[4];
+        if (gx >= 0 && gx + 3 < w) {
+            const unsigned char *pa = a + (size_t)sy * sa + (size_t)gx * CN;
+            const unsigned char *pb = b + (size_t)sy * sb + (size_t)gx * CN;
+            if (CN == 3) {
+                const U96 qa = *(const U96 *)pa, qb = *(const U96 *)pb;
+                const unsigned wa[3] = {qa.a, qa.b, qa.c}, wb[3] = {qb.a, qb.b, qb.c};
+                int ca[12], cb[12];
+#pragma unroll
+                for (int t = 0; t < 12; ++t) {
+                    ca[t] = (int)((wa[t >> 2] >> (8 * (t & 3))) & 0xFFu);
+                    cb[t] = (int)((wb[t >> 2] >> (8 * (t & 3))) & 0xFFu);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    ga[k] = gray_rgb(ca[3 * k], ca[3 * k + 1], ca[3 * k + 2], shift);
+                    gb[k] = gray_rgb(cb[3 * k], cb[3 * k + 1], cb[3 * k + 2], shift);
+                    const int dr = ca[3 * k] - cb[3 * k], dg = ca[3 * k + 1] - cb[3 * k + 1], db = ca[3 * k + 2] - cb[3 * k + 2];
+                    sq[k] = (unsigned)(dr * dr + dg * dg + db * db);
+                }
+            } else {
+                const unsigned qa = ((const U32U *)pa)->a, qb = ((const U32U *)pb)->a;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    ga[k] = (int)((qa >> (8 * k)) & 0xFFu);
+                    gb[k] = (int)((qb >> (8 * k)) & 0xFFu);
+                    const int d = ga[k] - gb[k];
+                    sq[k] = (unsigned)(d * d);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) load_gray_pair<CN>(a, sa, b, sb, sy, reflect101(gx + k, w), shift, ga[k], gb[k], sq[k]);
+        }
+        *(unsigned *)&gxs[ly][lx] = (unsigned)ga[0] | ((unsigned)ga[1] << 8) | ((unsigned)ga[2] << 16) | ((unsigned)ga[3] << 24);
+        *(unsigned *)&gys[ly][lx] = (unsigned)gb[0] | ((unsigned)gb[1] << 8) | ((unsigned)gb[2] << 16) | ((unsigned)gb[3] << 24);
+        if (want_sse && ly >= R && ly < R + TY && gy < ry1 && gy < h) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (lx + k >= R && lx + k < R + TX && gx + k < w) sse += sq[k];
+        }
+    }
+    return sse;
+}
+
+// 1 / d to full double precision without the IEEE division sequence (d is a product of positive SSIM terms)
+__device__ __forceinline__ double fast_recip(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+
 __device__ __forceinline__ double ssim_value(double ux, double uy, double spq, double dpq, double c1, double c2)
 {
     // spq = (P + Q) / 2 = uxx + uyy,  dpq = (P - Q) / 4 = uxy
     const double uxuy = ux * uy, uu = ux * ux + uy * uy;
     const double a1 = 2.0 * uxuy + c1, a2 = 2.0 * (dpq - uxuy) + c2;
     const double b1 = uu + c1, b2 = (spq - uu) + c2;
-    return (a1 * a2) / (b1 * b2);
+    return (a1 * a2) * fast_recip(b1 * b2);
 }
 
 template <int CN>
@@ -1185,25 +1264,15 @@ __global__ __launch_bounds__(256) void k_assess_gauss(const unsigned char *__res
                                                       const unsigned char *__restrict__ b, long long sb,
                                                       AssessParams P, double *__restrict__ part)
 {
-    __shared__ unsigned char gxs[AG_ROWS][AG_GP], gys[AG_ROWS][AG_GP];
+    __shared__ __attribute__((aligned(16))) unsigned char gxs[AG_ROWS][AG_GP];
+    __shared__ __attribute__((aligned(16))) unsigned char gys[AG_ROWS][AG_GP];
     __shared__ double H[4][AG_ROWS][AG_HP];
     __shared__ double red[4][3];
     const int tid = threadIdx.x;
     const int bx0 = blockIdx.x * AG_TX, by0 = P.ry0 + blockIdx.y * AG_TY;
     // ---- phase 1: gray halo tile (REFLECT_101 outside the image) + squared differences -----------
-    unsigned long long sse = 0;
-    for (int i = tid; i < AG_ROWS * AG_COLS; i += 256) {
-        const int ly = i / AG_COLS, lx = i - ly * AG_COLS;
-        const int gy = by0 - AG_R + ly, gx = bx0 - AG_R + lx;
-        const int sy = reflect101(gy, P.h), sx = reflect101(gx, P.w);
-        int ga, gb;
-        unsigned sq;
-        load_gray_pair<CN>(a, sa, b, sb, sy, sx, P.shift, ga, gb, sq);
-        gxs[ly][lx] = (unsigned char)ga;
-        gys[ly][lx] = (unsigned char)gb;
-        if (ly >= AG_R && ly < AG_R + AG_TY && lx >= AG_R && lx < AG_R + AG_TX && gy < P.ry1 && gy < P.h && gx < P.w)
-            sse += sq;
-    }
+    const unsigned long long sse = load_gray_tile<CN, AG_ROWS, AG_GP / 4, AG_GP, AG_R, AG_TX, AG_TY>(
+        a, sa, b, sb, P.h, P.w, P.shift, P.ry1, (P.flags & ASSESS_SSE) != 0, bx0, by0, gxs, gys);
     __syncthreads();
     // ---- phase 2: row pass, thread = (row, 8 output columns) ---------------------------------------
     {
@@ -1236,34 +1305,42 @@ __global__ __launch_bounds__(256) void k_assess_gauss(const unsigned char *__res
         }
     }
     __syncthreads();
-    // ---- phase 3: column pass + SSIM formula, thread = (column, 7 consecutive rows) --------------------
+    // ---- phase 3: column pass + SSIM formula, thread = (column, 7 consecutive rows); each filtered row is read
+    //      from LDS once and slides through registers --------------------------------------------------------------
     double sum_int = 0.0, sum_all = 0.0;
     {
         const int col = tid & 31, rg = tid >> 5;
         const int mx = bx0 + col;
-#pragma unroll 1
-        for (int r = 0; r < 7; ++r) {
-            const int orow = rg * 7 + r;
-            const int my = by0 + orow;
-            if (orow >= AG_TY || my >= P.ry1 || my >= P.h || mx >= P.w) break;
-            double u[4];
+        const int orow0 = rg * 7;
+        double u[4][7];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                double acc = H[m][orow + AG_R][col] * P.k[0];
+        for (int m = 0; m < 4; ++m) {
+            double hv[17];
 #pragma unroll
-                for (int j = 1; j <= AG_R; ++j)
-                    acc = fma(H[m][orow + AG_R - j][col] + H[m][orow + AG_R + j][col], P.k[j], acc);
-                u[m] = acc;
+            for (int i = 0; i < 17; ++i) hv[i] = H[m][min(orow0 + i, AG_ROWS - 1)][col];
+#pragma unroll
+            for (int r = 0; r < 7; ++r) {
+                double acc = hv[r + AG_R] * P.k[0];
+#pragma unroll
+                for (int j = 1; j <= AG_R; ++j) acc = fma(hv[r + AG_R - j] + hv[r + AG_R + j], P.k[j], acc);
+                u[m][r] = acc;
             }
-            const double spq = 0.5 * (u[2] + u[3]), dpq = 0.25 * (u[2] - u[3]);
-            const bool interior = my >= AG_R && my < P.h - AG_R && mx >= AG_R && mx < P.w - AG_R;
-            if (P.same_c) {
-                const double sv = ssim_value(u[0], u[1], spq, dpq, P.c1a, P.c2a);
-                sum_all += sv;
-                if (interior) sum_int += sv;
-            } else {
-                if (P.flags & ASSESS_SIMPLE) sum_all += ssim_value(u[0], u[1], spq, dpq, P.c1b, P.c2b);
-                if (interior && (P.flags & ASSESS_GAUSS)) sum_int += ssim_value(u[0], u[1], spq, dpq, P.c1a, P.c2a);
+        }
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            const int orow = orow0 + r;
+            const int my = by0 + orow;
+            if (orow < AG_TY && my < P.ry1 && my < P.h && mx < P.w) {
+                const double spq = 0.5 * (u[2][r] + u[3][r]), dpq = 0.25 * (u[2][r] - u[3][r]);
+                const bool interior = my >= AG_R && my < P.h - AG_R && mx >= AG_R && mx < P.w - AG_R;
+                if (P.same_c) {
+                    const double sv = ssim_value(u[0][r], u[1][r], spq, dpq, P.c1a, P.c2a);
+                    sum_all += sv;
+                    if (interior) sum_int += sv;
+                } else {
+                    if (P.flags & ASSESS_SIMPLE) sum_all += ssim_value(u[0][r], u[1][r], spq, dpq, P.c1b, P.c2b);
+                    if (interior && (P.flags & ASSESS_GAUSS)) sum_int += ssim_value(u[0][r], u[1][r], spq, dpq, P.c1a, P.c2a);
+                }
             }
         }
     }
@@ -1295,20 +1372,14 @@ __global__ __launch_bounds__(256) void k_assess_uniform(const unsigned char *__r
                                                         const unsigned char *__restrict__ b, long long sb,
                                                         AssessParams P, double *__restrict__ part)
 {
-    __shared__ unsigned char gxs[AU_ROWS][AU_GP], gys[AU_ROWS][AU_GP];
+    __shared__ __attribute__((aligned(16))) unsigned char gxs[AU_ROWS][AU_GP];
+    __shared__ __attribute__((aligned(16))) unsigned char gys[AU_ROWS][AU_GP];
     __shared__ int4 HS[AU_ROWS][AU_TX + 1];
     __shared__ double red[4];
     const int tid = threadIdx.x;
     const int bx0 = blockIdx.x * AU_TX, by0 = P.ry0 + blockIdx.y * AU_TY;
-    for (int i = tid; i < AU_ROWS * AU_COLS; i += 256) {
-        const int ly = i / AU_COLS, lx = i - ly * AU_COLS;
-        const int sy = reflect101(by0 - AU_R + ly, P.h), sx = reflect101(bx0 - AU_R + lx, P.w);
-        int ga, gb;
-        unsigned sq;
-        load_gray_pair<CN>(a, sa, b, sb, sy, sx, P.shift, ga, gb, sq);
-        gxs[ly][lx] = (unsigned char)ga;
-        gys[ly][lx] = (unsigned char)gb;
-    }
+    (void)load_gray_tile<CN, AU_ROWS, AU_GP / 4, AU_GP, AU_R, AU_TX, AU_TY>(a, sa, b, sb, P.h, P.w, P.shift, P.ry1, false, bx0,
+                                                                             by0, gxs, gys);
     __syncthreads();
     {   // row pass: sliding 7-tap integer sums, thread = (row, 8 output columns)
         const int row = tid >> 3, g = tid & 7;
@@ -1366,7 +1437,7 @@ __global__ __launch_bounds__(256) void k_assess_uniform(const unsigned char *__r
                 const double vx = cn * (uxx - ux * ux), vy = cn * (uyy - uy * uy), vxy = cn * (uxy - ux * uy);
                 const double a1 = 2.0 * ux * uy + P.c1a, a2 = 2.0 * vxy + P.c2a;
                 const double b1 = ux * ux + uy * uy + P.c1a, b2 = vx + vy + P.c2a;
-                sum += (a1 * a2) / (b1 * b2);
+                sum += (a1 * a2) * fast_recip(b1 * b2);
             }
             if (r < 6 && orow + 7 < AU_ROWS) {
                 const int4 vn = HS[orow + 7][col], vo = HS[orow][col];
