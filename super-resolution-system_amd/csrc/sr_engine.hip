@@ -246,15 +246,23 @@ struct TileSrc {
 enum { SRC_U8 = 0, SRC_F32 = 1, SRC_PLANAR = 2, SRC_LUT = 3 };
 
 // Source accessors for the pyrDown kernel -----------------------------------------------------
-struct __attribute__((packed, aligned(4))) F4A {   // 4 floats at any float-aligned address
-    float v[4];
-};
-struct __attribute__((packed, aligned(16))) F4V {  // 4 floats at a 16-byte aligned address
-    float v[4];
-};
-struct __attribute__((packed, aligned(1))) U96 {   // 12 bytes at any address
-    unsigned a, b, c;
-};
+// Vector load / store helpers.  The *_aN typedefs carry a reduced alignment so the compiler may emit one wide
+// global_load for an address that is only float- (or byte-) aligned; gfx950 handles those in hardware.
+typedef float f4_t __attribute__((ext_vector_type(4)));
+typedef float f2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u3_t __attribute__((ext_vector_type(3)));
+typedef f4_t f4_a4_t __attribute__((aligned(4)));    // 4 floats at any float-aligned address
+typedef f2_t f2_a8_t __attribute__((aligned(8)));
+typedef u3_t u3_a1_t __attribute__((aligned(1)));    // 12 bytes at any address
+typedef u4_t u4_a1_t __attribute__((aligned(1)));    // 16 bytes at any address
+typedef u4_t u4_a4_t __attribute__((aligned(4)));
+typedef unsigned u1_a1_t __attribute__((aligned(1)));
+
+__device__ __forceinline__ f4_t ld_f4_a4(const float *p) { return *(const f4_a4_t *)p; }
+__device__ __forceinline__ f4_t ld_f4(const float *p) { return *(const f4_t *)p; }
+__device__ __forceinline__ void st_f4(float *p, f4_t v) { *(f4_t *)p = v; }
+__device__ __forceinline__ u3_t ld_u3_a1(const void *p) { return *(const u3_a1_t *)p; }
 
 // One output pixel (all planes) of level lvl+1 from level lvl -- the generic form with every border rule.
 template <int SRC>
@@ -328,9 +336,6 @@ __global__ __launch_bounds__(256) void k_down(const TileDev *__restrict__ tiles,
 // once per plane with vector loads (u8: three byte-aligned 12-byte loads per row for all channels;
 // planar fp32: float2 + float4 + float4 + float), the row pass is evaluated once per input row and
 // shared by the two output rows.  Threads whose window touches a border use down_pixel per output.
-struct __attribute__((packed, aligned(8))) F2A {
-    float v[2];
-};
 
 template <int SRC, int CN>
 __global__ __launch_bounds__(256) void k_down_blk(const TileDev *__restrict__ tiles, const TileSrc *__restrict__ srcs,
@@ -367,13 +372,13 @@ __global__ __launch_bounds__(256) void k_down_blk(const TileDev *__restrict__ ti
             const unsigned char *row = (const unsigned char *)S.p + (size_t)(2 * y0 - 2 + rr) * S.stride + (size_t)(2 * x0 - 2) * CN;
             float s[11][CN];
             if (CN == 3) {
-                const U96 q0 = *(const U96 *)row, q1 = *(const U96 *)(row + 12), q2 = *(const U96 *)(row + 24);
-                const unsigned wds[9] = {q0.a, q0.b, q0.c, q1.a, q1.b, q1.c, q2.a, q2.b, q2.c};
+                const u3_t q0 = ld_u3_a1(row), q1 = ld_u3_a1(row + 12), q2 = ld_u3_a1(row + 24);
+                const unsigned wds[9] = {q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, q2.x, q2.y, q2.z};
 #pragma unroll
                 for (int b = 0; b < 33; ++b) s[b / 3][b % 3] = (float)((wds[b >> 2] >> (8 * (b & 3))) & 0xFFu);
             } else {
-                const U96 q0 = *(const U96 *)row;
-                const unsigned wds[3] = {q0.a, q0.b, q0.c};
+                const u3_t q0 = ld_u3_a1(row);
+                const unsigned wds[3] = {q0.x, q0.y, q0.z};
 #pragma unroll
                 for (int b = 0; b < 11; ++b) s[b][0] = (float)((wds[b >> 2] >> (8 * (b & 3))) & 0xFFu);
             }
@@ -387,14 +392,15 @@ __global__ __launch_bounds__(256) void k_down_blk(const TileDev *__restrict__ ti
         for (int c = 0; c < CN; ++c)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                if (j >= ny) break;
-                F4V o;
+                float o[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float v = ((hrow[2 * j + 2][c][k] * 6.0f + (hrow[2 * j + 1][c][k] + hrow[2 * j + 3][c][k]) * 4.0f) + hrow[2 * j][c][k]) + hrow[2 * j + 4][c][k];
-                    o.v[k] = v * (1.0f / 256.0f);
+                    o[k] = v * (1.0f / 256.0f);
                 }
-                *(F4V *)(dst + c * dplane + (size_t)j * po) = o;
+                f4_t ov;
+                ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
+                if (j < ny) st_f4(dst + c * dplane + (size_t)j * po, ov);
             }
     } else {  // SRC_PLANAR
         const int ps = T.P[lvl];
@@ -405,23 +411,24 @@ __global__ __launch_bounds__(256) void k_down_blk(const TileDev *__restrict__ ti
 #pragma unroll
             for (int r = 0; r < 7; ++r) {
                 const float *row = arena + T.g_off[lvl] + c * splane + (size_t)(2 * y0 - 2 + r) * ps + (2 * x0 - 2);
-                const F2A a = *(const F2A *)row;
-                const F4V b = *(const F4V *)(row + 2), d = *(const F4V *)(row + 6);
-                const float s[11] = {a.v[0], a.v[1], b.v[0], b.v[1], b.v[2], b.v[3], d.v[0], d.v[1], d.v[2], d.v[3], row[10]};
+                const f2_t a = *(const f2_a8_t *)row;
+                const f4_t b = ld_f4(row + 2), d = ld_f4(row + 6);
+                const float s[11] = {a.x, a.y, b.x, b.y, b.z, b.w, d.x, d.y, d.z, d.w, row[10]};
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     hrow[r][k] = ((s[2 * k + 2] * 6.0f + (s[2 * k + 1] + s[2 * k + 3]) * 4.0f) + s[2 * k]) + s[2 * k + 4];
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                if (j >= ny) break;
-                F4V o;
+                float o[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float v = ((hrow[2 * j + 2][k] * 6.0f + (hrow[2 * j + 1][k] + hrow[2 * j + 3][k]) * 4.0f) + hrow[2 * j][k]) + hrow[2 * j + 4][k];
-                    o.v[k] = v * (1.0f / 256.0f);
+                    o[k] = v * (1.0f / 256.0f);
                 }
-                *(F4V *)(dst + c * dplane + (size_t)j * po) = o;
+                f4_t ov;
+                ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
+                if (j < ny) st_f4(dst + c * dplane + (size_t)j * po, ov);
             }
         }
     }
@@ -597,17 +604,17 @@ __device__ __forceinline__ void up_block_interior(const float *__restrict__ plan
     float h[3][4];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-        const F4A q = *(const F4A *)(plane + (size_t)(r0 + r) * ps + c0);
+        const f4_t q = ld_f4_a4(plane + (size_t)(r0 + r) * ps + c0);
         if (!XO) {
-            h[r][0] = (q.v[0] + q.v[1] * 6.0f) + q.v[2];
-            h[r][1] = (q.v[1] + q.v[2]) * 4.0f;
-            h[r][2] = (q.v[1] + q.v[2] * 6.0f) + q.v[3];
-            h[r][3] = (q.v[2] + q.v[3]) * 4.0f;
+            h[r][0] = (q.x + q.y * 6.0f) + q.z;
+            h[r][1] = (q.y + q.z) * 4.0f;
+            h[r][2] = (q.y + q.z * 6.0f) + q.w;
+            h[r][3] = (q.z + q.w) * 4.0f;
         } else {
-            h[r][0] = (q.v[0] + q.v[1]) * 4.0f;
-            h[r][1] = (q.v[0] + q.v[1] * 6.0f) + q.v[2];
-            h[r][2] = (q.v[1] + q.v[2]) * 4.0f;
-            h[r][3] = (q.v[1] + q.v[2] * 6.0f) + q.v[3];
+            h[r][0] = (q.x + q.y) * 4.0f;
+            h[r][1] = (q.x + q.y * 6.0f) + q.z;
+            h[r][2] = (q.y + q.z) * 4.0f;
+            h[r][3] = (q.y + q.z * 6.0f) + q.w;
         }
     }
 #pragma unroll
@@ -648,8 +655,8 @@ __device__ __forceinline__ void gather_tile(const TileDev &T, const TileSrc S, c
         for (int j = 0; j < 2; ++j) {
             const char *srow = (const char *)S.p + (size_t)(ly0 + j) * S.stride;
             if (DT == SRC_U8 && CN == 3) {
-                const U96 q = *(const U96 *)(srow + (size_t)lx0 * 3);
-                const unsigned wds[3] = {q.a, q.b, q.c};
+                const u3_t q = ld_u3_a1(srow + (size_t)lx0 * 3);
+                const unsigned wds[3] = {q.x, q.y, q.z};
 #pragma unroll
                 for (int b = 0; b < 12; ++b) g0[j][b / 3][b % 3] = (float)((wds[b >> 2] >> (8 * (b & 3))) & 0xFFu);
             } else {
@@ -732,23 +739,22 @@ template <int CN, bool YO>
 __device__ __forceinline__ void up_level_thread(const TileDev &T, int lvl, float *__restrict__ arena, int x0, int y0,
                                                 int ny)
 {
-    const int w = T.W[lvl], h = T.H[lvl], p = T.P[lvl];
+    const int h = T.H[lvl], p = T.P[lvl];
     const size_t plane = (size_t)h * p;
     const int hs = T.H[lvl + 1], ws = T.W[lvl + 1], ps = T.P[lvl + 1];
     const size_t splane = (size_t)hs * ps;
     const int r0 = (y0 - 1) >> 1, c0 = (x0 - 1) >> 1;
     const bool interior = c0 >= 0 && c0 + 3 <= ws - 1 && r0 >= 0 && r0 + 2 <= hs - 1;
+    const bool two = ny > 1;
     const float *wrow = arena + T.w_off[lvl] + (size_t)y0 * p + x0;
-    F4V wv[2];
-    wv[0] = *(const F4V *)wrow;
-    wv[1] = (ny > 1) ? *(const F4V *)(wrow + p) : wv[0];
+    const f4_t w0v = ld_f4(wrow);
+    const f4_t w1v = two ? ld_f4(wrow + p) : w0v;
 #pragma unroll
     for (int c = 0; c < CN; ++c) {
         const float *g = arena + T.g_off[lvl] + c * plane + (size_t)y0 * p + x0;
         float *r = arena + T.r_off[lvl] + c * plane + (size_t)y0 * p + x0;
-        F4V gv[2];
-        gv[0] = *(const F4V *)g;
-        gv[1] = (ny > 1) ? *(const F4V *)(g + p) : gv[0];
+        const f4_t g0v = ld_f4(g);
+        const f4_t g1v = two ? ld_f4(g + p) : g0v;
         float ug[2][4], ur[2][4];
         const float *gs = arena + T.g_off[lvl + 1] + c * splane;
         const float *rs = arena + T.r_off[lvl + 1] + c * splane;
@@ -759,18 +765,17 @@ __device__ __forceinline__ void up_level_thread(const TileDev &T, int lvl, float
             up_block<false, YO>(gs, hs, ws, ps, r0, c0, ug);
             up_block<false, YO>(rs, hs, ws, ps, r0, c0, ur);
         }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (j >= ny) break;
-            F4V o;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float lap = gv[j].v[k] - ug[j][k];
-                const float wl = lap * wv[j].v[k];
-                o.v[k] = ur[j][k] + wl;
-            }
-            *(F4V *)(r + (size_t)j * p) = o;      // columns >= w land in the row padding (pitch is a multiple of 16)
-        }
+        f4_t o0, o1;
+        o0.x = ur[0][0] + (g0v.x - ug[0][0]) * w0v.x;
+        o0.y = ur[0][1] + (g0v.y - ug[0][1]) * w0v.y;
+        o0.z = ur[0][2] + (g0v.z - ug[0][2]) * w0v.z;
+        o0.w = ur[0][3] + (g0v.w - ug[0][3]) * w0v.w;
+        o1.x = ur[1][0] + (g1v.x - ug[1][0]) * w1v.x;
+        o1.y = ur[1][1] + (g1v.y - ug[1][1]) * w1v.y;
+        o1.z = ur[1][2] + (g1v.z - ug[1][2]) * w1v.z;
+        o1.w = ur[1][3] + (g1v.w - ug[1][3]) * w1v.w;
+        st_f4(r, o0);                  // columns >= w land in the row padding (pitch is a multiple of 16)
+        if (two) st_f4(r + p, o1);
     }
 }
 
@@ -787,14 +792,11 @@ __global__ __launch_bounds__(256) void k_up_level_blk(const TileDev *__restrict_
     if (lvl == T.nl - 1) {
         const size_t plane = (size_t)h * p;
         for (int j = 0; j < ny; ++j) {
-            const F4V wv = *(const F4V *)(arena + T.w_off[lvl] + (size_t)(y0 + j) * p + x0);
+            const f4_t wv = ld_f4(arena + T.w_off[lvl] + (size_t)(y0 + j) * p + x0);
 #pragma unroll
             for (int c = 0; c < CN; ++c) {
-                const F4V gv = *(const F4V *)(arena + T.g_off[lvl] + c * plane + (size_t)(y0 + j) * p + x0);
-                F4V o;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) o.v[k] = gv.v[k] * wv.v[k];
-                *(F4V *)(arena + T.r_off[lvl] + c * plane + (size_t)(y0 + j) * p + x0) = o;
+                const f4_t gv = ld_f4(arena + T.g_off[lvl] + c * plane + (size_t)(y0 + j) * p + x0);
+                st_f4(arena + T.r_off[lvl] + c * plane + (size_t)(y0 + j) * p + x0, gv * wv);
             }
         }
         return;
@@ -981,12 +983,6 @@ struct ExtractDesc {
     int out_w, out_h;
 };
 
-struct __attribute__((packed, aligned(1))) U128U {
-    unsigned a, b, c, d;
-};
-struct __attribute__((packed, aligned(4))) U128A {
-    unsigned a, b, c, d;
-};
 
 // One thread = 16 consecutive bytes of one output row.  Inside the source rectangle that is a straight
 // copy: one byte-aligned 16-byte load (the source offset x*cn is arbitrary) and one dword-aligned store;
@@ -1003,10 +999,8 @@ __global__ __launch_bounds__(256) void k_tile_extract(const unsigned char *__res
     const bool dst_al = ((((size_t)D.dst) | (size_t)D.dstride) & 3) == 0;
     if (r < D.h && b0 + 16 <= (long long)D.w * cn && dst_al) {
         const unsigned char *sp = img + (size_t)(D.y + r) * istride + (size_t)D.x * cn + b0;
-        const U128U v = *(const U128U *)sp;
-        U128A o;
-        o.a = v.a; o.b = v.b; o.c = v.c; o.d = v.d;
-        *(U128A *)d = o;
+        const u4_t v = *(const u4_a1_t *)sp;
+        *(u4_a4_t *)d = v;
         return;
     }
     const int nb = (int)min((long long)16, row_bytes - b0);
@@ -1171,9 +1165,6 @@ __device__ __forceinline__ void load_gray_pair(const unsigned char *__restrict__
     }
 }
 
-struct __attribute__((packed, aligned(1))) U32U {
-    unsigned a;
-};
 
 __device__ __forceinline__ int gray_rgb(int r, int g, int b, int shift)
 {
@@ -1201,8 +1192,8 @@ __device__ __forceinline__ unsigned long long load_gray_tile(const unsigned char
             const unsigned char *pa = a + (size_t)sy * sa + (size_t)gx * CN;
             const unsigned char *pb = b + (size_t)sy * sb + (size_t)gx * CN;
             if (CN == 3) {
-                const U96 qa = *(const U96 *)pa, qb = *(const U96 *)pb;
-                const unsigned wa[3] = {qa.a, qa.b, qa.c}, wb[3] = {qb.a, qb.b, qb.c};
+                const u3_t qa = ld_u3_a1(pa), qb = ld_u3_a1(pb);
+                const unsigned wa[3] = {qa.x, qa.y, qa.z}, wb[3] = {qb.x, qb.y, qb.z};
                 int ca[12], cb[12];
 #pragma unroll
                 for (int t = 0; t < 12; ++t) {
@@ -1217,7 +1208,7 @@ __device__ __forceinline__ unsigned long long load_gray_tile(const unsigned char
                     sq[k] = (unsigned)(dr * dr + dg * dg + db * db);
                 }
             } else {
-                const unsigned qa = ((const U32U *)pa)->a, qb = ((const U32U *)pb)->a;
+                const unsigned qa = *(const u1_a1_t *)pa, qb = *(const u1_a1_t *)pb;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     ga[k] = (int)((qa >> (8 * k)) & 0xFFu);
@@ -1276,7 +1267,7 @@ __global__ __launch_bounds__(256) void k_assess_gauss(const unsigned char *__res
     __syncthreads();
     // ---- phase 2: row pass, thread = (row, 8 output columns) ---------------------------------------
     {
-        const int row = tid >> 2, g = tid & 3;
+        const int row = tid & 63, g = tid >> 6;      // lanes walk rows: H row pitch 33 doubles -> conflict-free writes
         int xv[18], yv[18], pv[18], qv[18];
 #pragma unroll
         for (int i = 0; i < 18; ++i) {
@@ -1365,7 +1356,7 @@ __global__ __launch_bounds__(256) void k_assess_gauss(const unsigned char *__res
 #define AU_R 3
 #define AU_ROWS (AU_TY + 2 * AU_R) /* 32 */
 #define AU_COLS (AU_TX + 2 * AU_R) /* 70 */
-#define AU_GP 72
+#define AU_GP 76                   /* 19 dwords: odd pitch, rows across lanes read conflict-free */
 
 template <int CN>
 __global__ __launch_bounds__(256) void k_assess_uniform(const unsigned char *__restrict__ a, long long sa,
@@ -1374,15 +1365,15 @@ __global__ __launch_bounds__(256) void k_assess_uniform(const unsigned char *__r
 {
     __shared__ __attribute__((aligned(16))) unsigned char gxs[AU_ROWS][AU_GP];
     __shared__ __attribute__((aligned(16))) unsigned char gys[AU_ROWS][AU_GP];
-    __shared__ int4 HS[AU_ROWS][AU_TX + 1];
+    __shared__ int4 HS[AU_TX][AU_ROWS + 1];      // column-major: lanes walk rows in the row pass, columns in the column pass
     __shared__ double red[4];
     const int tid = threadIdx.x;
     const int bx0 = blockIdx.x * AU_TX, by0 = P.ry0 + blockIdx.y * AU_TY;
-    (void)load_gray_tile<CN, AU_ROWS, AU_GP / 4, AU_GP, AU_R, AU_TX, AU_TY>(a, sa, b, sb, P.h, P.w, P.shift, P.ry1, false, bx0,
+    (void)load_gray_tile<CN, AU_ROWS, 18, AU_GP, AU_R, AU_TX, AU_TY>(a, sa, b, sb, P.h, P.w, P.shift, P.ry1, false, bx0,
                                                                              by0, gxs, gys);
     __syncthreads();
     {   // row pass: sliding 7-tap integer sums, thread = (row, 8 output columns)
-        const int row = tid >> 3, g = tid & 7;
+        const int row = tid & 31, g = tid >> 5;
         int xv[14], yv[14], xx[14], yy[14], xy[14];
 #pragma unroll
         for (int i = 0; i < 14; ++i) {
@@ -1403,7 +1394,7 @@ __global__ __launch_bounds__(256) void k_assess_uniform(const unsigned char *__r
         }
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
-            HS[row][8 * g + o] = make_int4(sx | (sy << 16), sxx, syy, sxy);
+            HS[8 * g + o][row] = make_int4(sx | (sy << 16), sxx, syy, sxy);
             if (o < 7) {
                 sx = sx + xv[o + 7] - xv[o];
                 sy = sy + yv[o + 7] - yv[o];
@@ -1422,7 +1413,7 @@ __global__ __launch_bounds__(256) void k_assess_uniform(const unsigned char *__r
         int t0 = 0, t1 = 0, t2 = 0, t3 = 0;
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
-            const int4 v = HS[min(r_first + i, AU_ROWS - 1)][col];
+            const int4 v = HS[col][min(r_first + i, AU_ROWS - 1)];
             t0 += v.x; t1 += v.y; t2 += v.z; t3 += v.w;
         }
         const double inv = 1.0 / 49.0, cn = 49.0 / 48.0;
@@ -1440,7 +1431,7 @@ __global__ __launch_bounds__(256) void k_assess_uniform(const unsigned char *__r
                 sum += (a1 * a2) * fast_recip(b1 * b2);
             }
             if (r < 6 && orow + 7 < AU_ROWS) {
-                const int4 vn = HS[orow + 7][col], vo = HS[orow][col];
+                const int4 vn = HS[col][orow + 7], vo = HS[col][orow];
                 t0 += vn.x - vo.x; t1 += vn.y - vo.y; t2 += vn.z - vo.z; t3 += vn.w - vo.w;
             }
         }
