@@ -243,17 +243,6 @@ struct TileSrc {
     long long stride;
 };
 
-// What the final gather needs of one tile, 80 bytes = 5 x 16: staged into LDS for the candidates of a block.
-struct FinalDesc {
-    int x, y, w, h;
-    int fw, lut_off, nl, pad0;
-    int H1, W1, P1, pad1;
-    long long g1, r1;      // float offsets of plane 0 of G_1 / R_1 in the arena
-    const void *src;       // level-0 tile data (row 0, possibly virtual) and its row stride in bytes
-    long long stride;
-};
-static_assert(sizeof(FinalDesc) == 80, "FinalDesc is copied as five 16-byte words");
-
 enum { SRC_U8 = 0, SRC_F32 = 1, SRC_PLANAR = 2, SRC_LUT = 3 };
 
 // Source accessors for the pyrDown kernel -----------------------------------------------------
@@ -642,20 +631,20 @@ __device__ __forceinline__ void up_block_interior(const float *__restrict__ plan
 }
 
 // Is the thread's 4 x 2 rectangle (tile-local origin lx0, ly0; nx x ny of it on the canvas strip) an
-// "interior" visit of tile D: all eight pixels inside the tile and every level-1 tap away from the borders?
+// "interior" visit of tile T: all eight pixels inside the tile and every level-1 tap away from the borders?
 // Interior visits run in k_final_fast, everything else in k_final_edge; both kernels evaluate this same test.
 template <bool LAP>
-__device__ __forceinline__ bool visit_is_interior(const FinalDesc &D, int lx0, int ly0, int nx, int ny)
+__device__ __forceinline__ bool visit_is_interior(const TileDev &T, int lx0, int ly0, int nx, int ny)
 {
-    if (nx != 4 || ny != 2 || lx0 < 0 || ly0 < 0 || lx0 + 3 >= D.w || ly0 + 1 >= D.h) return false;
-    if (LAP && D.nl > 1) {
+    if (nx != 4 || ny != 2 || lx0 < 0 || ly0 < 0 || lx0 + 3 >= T.w || ly0 + 1 >= T.h) return false;
+    if (LAP && T.nl > 1) {
         const int r0 = (ly0 - 1) >> 1, c0 = (lx0 - 1) >> 1;
-        return c0 >= 0 && c0 + 3 <= D.W1 - 1 && r0 >= 0 && r0 + 2 <= D.H1 - 1;
+        return c0 >= 0 && c0 + 3 <= T.W[1] - 1 && r0 >= 0 && r0 + 2 <= T.H[1] - 1;
     }
     return true;
 }
 
-__device__ __forceinline__ void tile_weights(const FinalDesc &D, const float *__restrict__ luts, int lx0, int ly0,
+__device__ __forceinline__ void tile_weights(const TileDev &T, const float *__restrict__ luts, int lx0, int ly0,
                                              float (&w0)[2][4])
 {
 #pragma unroll
@@ -663,71 +652,32 @@ __device__ __forceinline__ void tile_weights(const FinalDesc &D, const float *__
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int lx = lx0 + k, ly = ly0 + j;
-            const int d = min(min(ly, D.h - 1 - ly), min(lx, D.w - 1 - lx));
-            w0[j][k] = luts[D.lut_off + min(max(d, 0), D.fw)];
+            const int d = min(min(ly, T.h - 1 - ly), min(lx, T.w - 1 - lx));
+            w0[j][k] = luts[T.lut_off + min(max(d, 0), T.fw)];
         }
 }
 
-// pyrUp of one 3 x 4 register neighbourhood (rows q[0..2]) -> the thread's 2 x 4 pixels (interior form)
-template <bool XO, bool YO>
-__device__ __forceinline__ void up_regs(const f4_t (&q)[3], float (&u)[2][4])
-{
-    float h[3][4];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        if (!XO) {
-            h[r][0] = (q[r].x + q[r].y * 6.0f) + q[r].z;
-            h[r][1] = (q[r].y + q[r].z) * 4.0f;
-            h[r][2] = (q[r].y + q[r].z * 6.0f) + q[r].w;
-            h[r][3] = (q[r].z + q[r].w) * 4.0f;
-        } else {
-            h[r][0] = (q[r].x + q[r].y) * 4.0f;
-            h[r][1] = (q[r].x + q[r].y * 6.0f) + q[r].z;
-            h[r][2] = (q[r].y + q[r].z) * 4.0f;
-            h[r][3] = (q[r].y + q[r].z * 6.0f) + q[r].w;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float ev = ((h[0][k] + h[1][k] * 6.0f) + h[2][k]) * (1.0f / 64.0f);
-        if (!YO) {
-            u[0][k] = ev;
-            u[1][k] = ((h[1][k] + h[2][k]) * 4.0f) * (1.0f / 64.0f);
-        } else {
-            u[0][k] = ((h[0][k] + h[1][k]) * 4.0f) * (1.0f / 64.0f);
-            u[1][k] = ev;
-        }
-    }
-}
-
-// interior visit: every global load of the visit is issued before the first use, then straight-line arithmetic
+// interior visit: straight-line code, vector loads, no border selects
 template <int DT, bool LAP, int CN, bool XO, bool YO>
-__device__ __forceinline__ void gather_tile_fast(const FinalDesc &D, const float *__restrict__ arena,
+__device__ __forceinline__ void gather_tile_fast(const TileDev &T, const TileSrc S, const float *__restrict__ arena,
                                                  const float *__restrict__ luts, int lx0, int ly0,
                                                  float (&acc)[2][4][CN], float (&wacc)[2][4])
 {
+    float w0[2][4];
+    tile_weights(T, luts, lx0, ly0, w0);
     const int r0 = (ly0 - 1) >> 1, c0 = (lx0 - 1) >> 1;
-    const bool pyr = LAP && D.nl > 1;
-    const size_t splane = (size_t)D.H1 * D.P1;
-    // ---- loads -----------------------------------------------------------------------------------------
-    f4_t qg[CN][3], qr[CN][3];
-    if (pyr) {
-        const size_t o = (size_t)r0 * D.P1 + c0;
-#pragma unroll
-        for (int c = 0; c < CN; ++c)
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                qg[c][r] = ld_f4_a4(arena + D.g1 + c * splane + o + (size_t)r * D.P1);
-                qr[c][r] = ld_f4_a4(arena + D.r1 + c * splane + o + (size_t)r * D.P1);
-            }
-    }
+    const bool pyr = LAP && T.nl > 1;
+    const int hs = T.H[1], ps = T.P[1];
+    const size_t splane = (size_t)hs * ps;
     float g0[2][4][CN];
-    u3_t qs[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const char *srow = (const char *)D.src + (size_t)(ly0 + j) * D.stride;
+        const char *srow = (const char *)S.p + (size_t)(ly0 + j) * S.stride;
         if (DT == SRC_U8 && CN == 3) {
-            qs[j] = ld_u3_a1(srow + (size_t)lx0 * 3);
+            const u3_t q = ld_u3_a1(srow + (size_t)lx0 * 3);
+            const unsigned wds[3] = {q.x, q.y, q.z};
+#pragma unroll
+            for (int b = 0; b < 12; ++b) g0[j][b / 3][b % 3] = (float)((wds[b >> 2] >> (8 * (b & 3))) & 0xFFu);
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -738,23 +688,12 @@ __device__ __forceinline__ void gather_tile_fast(const FinalDesc &D, const float
                 }
         }
     }
-    float w0[2][4];
-    tile_weights(D, luts, lx0, ly0, w0);
-    // ---- arithmetic ----------------------------------------------------------------------------------------
-    if (DT == SRC_U8 && CN == 3) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const unsigned wds[3] = {qs[j].x, qs[j].y, qs[j].z};
-#pragma unroll
-            for (int b = 0; b < 12; ++b) g0[j][b / 3][b % 3] = (float)((wds[b >> 2] >> (8 * (b & 3))) & 0xFFu);
-        }
-    }
 #pragma unroll
     for (int c = 0; c < CN; ++c) {
         float ug[2][4], ur[2][4];
         if (pyr) {
-            up_regs<XO, YO>(qg[c], ug);
-            up_regs<XO, YO>(qr[c], ur);
+            up_block_interior<XO, YO>(arena + T.g_off[1] + c * splane, ps, r0, c0, ug);
+            up_block_interior<XO, YO>(arena + T.r_off[1] + c * splane, ps, r0, c0, ur);
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -779,29 +718,29 @@ __device__ __forceinline__ void gather_tile_fast(const FinalDesc &D, const float
 
 // any visit: clamped taps, border selects, per-pixel validity (tile / level borders, ragged canvas edges)
 template <int DT, bool LAP, int CN, bool XO, bool YO>
-__device__ __forceinline__ void gather_tile_generic(const FinalDesc &D, const float *__restrict__ arena,
+__device__ __forceinline__ void gather_tile_generic(const TileDev &T, const TileSrc S, const float *__restrict__ arena,
                                                     const float *__restrict__ luts, int lx0, int ly0, unsigned valid,
                                                     float (&acc)[2][4][CN], float (&wacc)[2][4])
 {
     float w0[2][4];
-    tile_weights(D, luts, lx0, ly0, w0);
+    tile_weights(T, luts, lx0, ly0, w0);
     const int r0 = (ly0 - 1) >> 1, c0 = (lx0 - 1) >> 1;
-    const bool pyr = LAP && D.nl > 1;
-    const int hs = D.H1, ws = D.W1, ps = D.P1;
+    const bool pyr = LAP && T.nl > 1;
+    const int hs = T.H[1], ws = T.W[1], ps = T.P[1];
     const size_t splane = (size_t)hs * ps;
 #pragma unroll
     for (int c = 0; c < CN; ++c) {
         float ug[2][4], ur[2][4];
         if (pyr) {
-            up_block<XO, YO>(arena + D.g1 + c * splane, hs, ws, ps, r0, c0, ug);
-            up_block<XO, YO>(arena + D.r1 + c * splane, hs, ws, ps, r0, c0, ur);
+            up_block<XO, YO>(arena + T.g_off[1] + c * splane, hs, ws, ps, r0, c0, ug);
+            up_block<XO, YO>(arena + T.r_off[1] + c * splane, hs, ws, ps, r0, c0, ur);
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (!(valid & (1u << (j * 4 + k)))) continue;
-                const char *srow = (const char *)D.src + (size_t)(ly0 + j) * D.stride;
+                const char *srow = (const char *)S.p + (size_t)(ly0 + j) * S.stride;
                 float g0;
                 if (DT == SRC_U8) g0 = (float)((const unsigned char *)srow)[(lx0 + k) * CN + c];
                 else g0 = ((const float *)srow)[(lx0 + k) * CN + c];
@@ -896,12 +835,12 @@ __global__ __launch_bounds__(256) void k_up_level_blk(const TileDev *__restrict_
     else up_level_thread<CN, false>(T, lvl, arena, x0, y0, ny);
 }
 
-#define FINAL_MAX_CAND 48
+#define FINAL_MAX_CAND 64
 
-// Candidate tiles of one 256 x 8 pixel block, in list order (wave 0, ballot-compacted), and their descriptors
-// copied into LDS.  Returns the count (> FINAL_MAX_CAND: list overflowed, walk every tile from global memory).
-__device__ __forceinline__ int block_candidates(const FinalDesc *__restrict__ descs, int n, int bx0, int by0, int bx1,
-                                                int by1, int *s_cnt, int *s_list, FinalDesc *s_desc)
+// Candidate tiles of one 256 x 8 pixel block, in list order (wave 0, ballot-compacted).  Returns the count
+// (> FINAL_MAX_CAND: list overflowed, walk every tile).
+__device__ __forceinline__ int block_candidates(const TileDev *__restrict__ tiles, int n, int bx0, int by0, int bx1,
+                                                int by1, int *s_cnt, int *s_list)
 {
     const int tid = threadIdx.y * 64 + threadIdx.x;
     if (tid < 64) {
@@ -910,8 +849,8 @@ __device__ __forceinline__ int block_candidates(const FinalDesc *__restrict__ de
             const int t = base + tid;
             bool hit = false;
             if (t < n) {
-                const int4 r = *(const int4 *)&descs[t];      // x, y, w, h
-                hit = r.x < bx1 && r.x + r.z > bx0 && r.y < by1 && r.y + r.w > by0;
+                const int4 r = *(const int4 *)&tiles[t];      // h, w, x, y
+                hit = r.z < bx1 && r.z + r.y > bx0 && r.w < by1 && r.w + r.x > by0;
             }
             const unsigned long long m = __ballot(hit);
             if (hit) {
@@ -923,15 +862,7 @@ __device__ __forceinline__ int block_candidates(const FinalDesc *__restrict__ de
         if (tid == 0) *s_cnt = cnt;
     }
     __syncthreads();
-    const int cnt = *s_cnt;
-    if (cnt <= FINAL_MAX_CAND) {
-        for (int i = tid; i < cnt * 5; i += 256) {
-            const int e = i / 5, q = i - e * 5;
-            ((int4 *)s_desc)[i] = ((const int4 *)&descs[s_list[e]])[q];
-        }
-        __syncthreads();
-    }
-    return cnt;
+    return *s_cnt;
 }
 
 // normalise, clip, truncate and store the thread's pixels
@@ -974,29 +905,28 @@ __device__ __forceinline__ void store_pixels(const float (&acc)[2][4][CN], const
 // Final gather, pass 1: threads all of whose tile visits are interior.  Threads with any border visit leave
 // their pixels to k_final_edge.
 template <int DT, bool LAP, int CN>
-__global__ __launch_bounds__(256, 3) void k_final_fast(const FinalDesc *__restrict__ descs, int n,
-                                                       const float *__restrict__ arena, const float *__restrict__ luts,
-                                                       unsigned char *__restrict__ canvas, long long cstride,
-                                                       float *__restrict__ canvas_f32, int cw, int row_begin, int row_end)
+__global__ __launch_bounds__(256, 3) void k_final_fast(const TileDev *__restrict__ tiles, const TileSrc *__restrict__ srcs,
+                                                    int n, const float *__restrict__ arena,
+                                                    const float *__restrict__ luts, unsigned char *__restrict__ canvas,
+                                                    long long cstride, float *__restrict__ canvas_f32, int cw,
+                                                    int row_begin, int row_end)
 {
     __shared__ int s_cnt;
     __shared__ int s_list[FINAL_MAX_CAND];
-    __shared__ FinalDesc s_desc[FINAL_MAX_CAND];
     const int bx0 = blockIdx.x * 256, by0 = row_begin + blockIdx.y * 8;
-    const int ncand = block_candidates(descs, n, bx0, by0, min(bx0 + 256, cw), min(by0 + 8, row_end), &s_cnt, s_list, s_desc);
+    const int ncand = block_candidates(tiles, n, bx0, by0, min(bx0 + 256, cw), min(by0 + 8, row_end), &s_cnt, s_list);
     const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int y0 = row_begin + (blockIdx.y * 4 + threadIdx.y) * 2;
     if (x0 >= cw || y0 >= row_end) return;
     const int nx = min(4, cw - x0), ny = min(2, row_end - y0);
     const bool overflow = ncand > FINAL_MAX_CAND;
-    const FinalDesc *dl = overflow ? descs : s_desc;
     const int nloop = overflow ? n : ncand;
     // visit classification first: one border visit sends the whole thread to the edge pass
     for (int i = 0; i < nloop; ++i) {
-        const int4 r = *(const int4 *)&dl[i];                // x, y, w, h
-        const int lx0 = x0 - r.x, ly0 = y0 - r.y;
-        if (lx0 + nx <= 0 || ly0 + ny <= 0 || lx0 >= r.z || ly0 >= r.w) continue;
-        if (!visit_is_interior<LAP>(dl[i], lx0, ly0, nx, ny)) return;
+        const TileDev &T = tiles[overflow ? i : s_list[i]];
+        const int lx0 = x0 - T.x, ly0 = y0 - T.y;
+        if (lx0 + nx <= 0 || ly0 + ny <= 0 || lx0 >= T.w || ly0 >= T.h) continue;
+        if (!visit_is_interior<LAP>(T, lx0, ly0, nx, ny)) return;
     }
     float acc[2][4][CN], wacc[2][4];
 #pragma unroll
@@ -1008,15 +938,17 @@ __global__ __launch_bounds__(256, 3) void k_final_fast(const FinalDesc *__restri
             for (int c = 0; c < CN; ++c) acc[j][k][c] = 0.f;
         }
     for (int i = 0; i < nloop; ++i) {
-        const FinalDesc D = dl[i];
-        const int lx0 = x0 - D.x, ly0 = y0 - D.y;
-        if (lx0 + 4 <= 0 || ly0 + 2 <= 0 || lx0 >= D.w || ly0 >= D.h) continue;
-        const bool xo = (D.x & 1) != 0;                      // x0 is a multiple of 4
-        const bool yo = ((row_begin - D.y) & 1) != 0;        // y0 - row_begin is a multiple of 2
-        if (!xo && !yo) gather_tile_fast<DT, LAP, CN, false, false>(D, arena, luts, lx0, ly0, acc, wacc);
-        else if (xo && !yo) gather_tile_fast<DT, LAP, CN, true, false>(D, arena, luts, lx0, ly0, acc, wacc);
-        else if (!xo && yo) gather_tile_fast<DT, LAP, CN, false, true>(D, arena, luts, lx0, ly0, acc, wacc);
-        else gather_tile_fast<DT, LAP, CN, true, true>(D, arena, luts, lx0, ly0, acc, wacc);
+        const int t = overflow ? i : s_list[i];
+        const TileDev &T = tiles[t];
+        const int lx0 = x0 - T.x, ly0 = y0 - T.y;
+        if (lx0 + 4 <= 0 || ly0 + 2 <= 0 || lx0 >= T.w || ly0 >= T.h) continue;
+        const bool xo = (T.x & 1) != 0;                      // x0 is a multiple of 4
+        const bool yo = ((row_begin - T.y) & 1) != 0;        // y0 - row_begin is a multiple of 2
+        const TileSrc S = srcs[t];
+        if (!xo && !yo) gather_tile_fast<DT, LAP, CN, false, false>(T, S, arena, luts, lx0, ly0, acc, wacc);
+        else if (xo && !yo) gather_tile_fast<DT, LAP, CN, true, false>(T, S, arena, luts, lx0, ly0, acc, wacc);
+        else if (!xo && yo) gather_tile_fast<DT, LAP, CN, false, true>(T, S, arena, luts, lx0, ly0, acc, wacc);
+        else gather_tile_fast<DT, LAP, CN, true, true>(T, S, arena, luts, lx0, ly0, acc, wacc);
     }
     store_pixels<CN>(acc, wacc, canvas, cstride, canvas_f32, cw, x0, y0, nx, ny);
 }
@@ -1024,29 +956,28 @@ __global__ __launch_bounds__(256, 3) void k_final_fast(const FinalDesc *__restri
 // Final gather, pass 2: the threads pass 1 left out (a border visit).  Blocks that no tile border crosses
 // return right after the candidate scan.
 template <int DT, bool LAP, int CN>
-__global__ __launch_bounds__(256) void k_final_edge(const FinalDesc *__restrict__ descs, int n,
-                                                    const float *__restrict__ arena, const float *__restrict__ luts,
-                                                    unsigned char *__restrict__ canvas, long long cstride,
-                                                    float *__restrict__ canvas_f32, int cw, int row_begin, int row_end)
+__global__ __launch_bounds__(256) void k_final_edge(const TileDev *__restrict__ tiles, const TileSrc *__restrict__ srcs,
+                                                    int n, const float *__restrict__ arena,
+                                                    const float *__restrict__ luts, unsigned char *__restrict__ canvas,
+                                                    long long cstride, float *__restrict__ canvas_f32, int cw,
+                                                    int row_begin, int row_end)
 {
     __shared__ int s_cnt;
     __shared__ int s_list[FINAL_MAX_CAND];
-    __shared__ FinalDesc s_desc[FINAL_MAX_CAND];
     const int bx0 = blockIdx.x * 256, by0 = row_begin + blockIdx.y * 8;
-    const int ncand = block_candidates(descs, n, bx0, by0, min(bx0 + 256, cw), min(by0 + 8, row_end), &s_cnt, s_list, s_desc);
+    const int ncand = block_candidates(tiles, n, bx0, by0, min(bx0 + 256, cw), min(by0 + 8, row_end), &s_cnt, s_list);
     const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int y0 = row_begin + (blockIdx.y * 4 + threadIdx.y) * 2;
     if (x0 >= cw || y0 >= row_end) return;
     const int nx = min(4, cw - x0), ny = min(2, row_end - y0);
     const bool overflow = ncand > FINAL_MAX_CAND;
-    const FinalDesc *dl = overflow ? descs : s_desc;
     const int nloop = overflow ? n : ncand;
     bool edge = false;
     for (int i = 0; i < nloop; ++i) {
-        const int4 r = *(const int4 *)&dl[i];
-        const int lx0 = x0 - r.x, ly0 = y0 - r.y;
-        if (lx0 + nx <= 0 || ly0 + ny <= 0 || lx0 >= r.z || ly0 >= r.w) continue;
-        if (!visit_is_interior<LAP>(dl[i], lx0, ly0, nx, ny)) edge = true;
+        const TileDev &T = tiles[overflow ? i : s_list[i]];
+        const int lx0 = x0 - T.x, ly0 = y0 - T.y;
+        if (lx0 + nx <= 0 || ly0 + ny <= 0 || lx0 >= T.w || ly0 >= T.h) continue;
+        if (!visit_is_interior<LAP>(T, lx0, ly0, nx, ny)) edge = true;
     }
     if (!edge) return;
     float acc[2][4][CN], wacc[2][4];
@@ -1059,22 +990,24 @@ __global__ __launch_bounds__(256) void k_final_edge(const FinalDesc *__restrict_
             for (int c = 0; c < CN; ++c) acc[j][k][c] = 0.f;
         }
     for (int i = 0; i < nloop; ++i) {
-        const FinalDesc D = dl[i];
-        const int lx0 = x0 - D.x, ly0 = y0 - D.y;
-        if (lx0 + nx <= 0 || ly0 + ny <= 0 || lx0 >= D.w || ly0 >= D.h) continue;
+        const int t = overflow ? i : s_list[i];
+        const TileDev &T = tiles[t];
+        const int lx0 = x0 - T.x, ly0 = y0 - T.y;
+        if (lx0 + nx <= 0 || ly0 + ny <= 0 || lx0 >= T.w || ly0 >= T.h) continue;
         unsigned valid = 0;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (j < ny && k < nx && lx0 + k >= 0 && lx0 + k < D.w && ly0 + j >= 0 && ly0 + j < D.h)
+                if (j < ny && k < nx && lx0 + k >= 0 && lx0 + k < T.w && ly0 + j >= 0 && ly0 + j < T.h)
                     valid |= 1u << (j * 4 + k);
-        const bool xo = (D.x & 1) != 0;
-        const bool yo = ((row_begin - D.y) & 1) != 0;
-        if (!xo && !yo) gather_tile_generic<DT, LAP, CN, false, false>(D, arena, luts, lx0, ly0, valid, acc, wacc);
-        else if (xo && !yo) gather_tile_generic<DT, LAP, CN, true, false>(D, arena, luts, lx0, ly0, valid, acc, wacc);
-        else if (!xo && yo) gather_tile_generic<DT, LAP, CN, false, true>(D, arena, luts, lx0, ly0, valid, acc, wacc);
-        else gather_tile_generic<DT, LAP, CN, true, true>(D, arena, luts, lx0, ly0, valid, acc, wacc);
+        const bool xo = (T.x & 1) != 0;
+        const bool yo = ((row_begin - T.y) & 1) != 0;
+        const TileSrc S = srcs[t];
+        if (!xo && !yo) gather_tile_generic<DT, LAP, CN, false, false>(T, S, arena, luts, lx0, ly0, valid, acc, wacc);
+        else if (xo && !yo) gather_tile_generic<DT, LAP, CN, true, false>(T, S, arena, luts, lx0, ly0, valid, acc, wacc);
+        else if (!xo && yo) gather_tile_generic<DT, LAP, CN, false, true>(T, S, arena, luts, lx0, ly0, valid, acc, wacc);
+        else gather_tile_generic<DT, LAP, CN, true, true>(T, S, arena, luts, lx0, ly0, valid, acc, wacc);
     }
     store_pixels<CN>(acc, wacc, canvas, cstride, canvas_f32, cw, x0, y0, nx, ny);
 }
@@ -1811,8 +1744,6 @@ struct sr_blend_plan {
     float *d_arena = nullptr;
     TileDev *d_tiles = nullptr, *d_classes = nullptr;
     TileSrc *d_srcs = nullptr;
-    FinalDesc *d_fdesc = nullptr;
-    std::vector<FinalDesc> fdesc;
     float *d_luts = nullptr;
     // launch extents per level
     int max_w[SR_MAX_LEVELS] = {0}, max_grows[SR_MAX_LEVELS] = {0}, max_rrows[SR_MAX_LEVELS] = {0};
@@ -2159,7 +2090,6 @@ int sr_blend_plan_destroy(sr_blend_plan *plan)
         if (plan->d_tiles) (void)hipFree(plan->d_tiles);
         if (plan->d_classes) (void)hipFree(plan->d_classes);
         if (plan->d_srcs) (void)hipFree(plan->d_srcs);
-        if (plan->d_fdesc) (void)hipFree(plan->d_fdesc);
         if (plan->d_luts) (void)hipFree(plan->d_luts);
     }
     delete plan;
@@ -2314,17 +2244,6 @@ int sr_blend_plan_create(sr_ctx *ctx, const sr_tile_rect *h_tiles, int n, int cn
     if ((e = hipMalloc((void **)&P->d_tiles, sizeof(TileDev) * n)) != hipSuccess) return fail(e, "tile table");
     if ((e = hipMalloc((void **)&P->d_classes, sizeof(TileDev) * P->classes.size())) != hipSuccess) return fail(e, "class table");
     if ((e = hipMalloc((void **)&P->d_srcs, sizeof(TileSrc) * n)) != hipSuccess) return fail(e, "src table");
-    if ((e = hipMalloc((void **)&P->d_fdesc, sizeof(FinalDesc) * n)) != hipSuccess) return fail(e, "final table");
-    P->fdesc.resize(n);
-    for (int t = 0; t < n; ++t) {
-        const TileDev &T = P->tiles[t];
-        FinalDesc &D = P->fdesc[t];
-        memset(&D, 0, sizeof(D));
-        D.x = T.x; D.y = T.y; D.w = T.w; D.h = T.h;
-        D.fw = T.fw; D.lut_off = T.lut_off; D.nl = T.nl;
-        D.H1 = T.nl > 1 ? T.H[1] : 1; D.W1 = T.nl > 1 ? T.W[1] : 1; D.P1 = T.nl > 1 ? T.P[1] : 16;
-        D.g1 = T.nl > 1 ? T.g_off[1] : 0; D.r1 = T.nl > 1 ? T.r_off[1] : 0;
-    }
     if ((e = hipMalloc((void **)&P->d_luts, sizeof(float) * P->luts.size())) != hipSuccess) return fail(e, "luts");
     if ((e = hipMemcpyAsync(P->d_tiles, P->tiles.data(), sizeof(TileDev) * n, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e, "upload");
     if ((e = hipMemcpyAsync(P->d_classes, P->classes.data(), sizeof(TileDev) * P->classes.size(), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e, "upload");
@@ -2369,11 +2288,6 @@ static int blend_impl(sr_blend_plan *P, bool lap, int dtype, void *const *h_d_ti
         srcs[t].stride = h_strides[t];
     }
     HIPCHK(upload_small(ctx, P->d_srcs, srcs.data(), sizeof(TileSrc) * P->n));
-    for (int t = 0; t < P->n; ++t) {
-        P->fdesc[t].src = h_d_tiles[t];
-        P->fdesc[t].stride = h_strides[t];
-    }
-    HIPCHK(upload_small(ctx, P->d_fdesc, P->fdesc.data(), sizeof(FinalDesc) * P->n));
     const int rows = P->row_end - P->row_begin;
     if (rows <= 0) return SR_OK;
     dim3 block(64, 4);
@@ -2434,10 +2348,10 @@ static int blend_impl(sr_blend_plan *P, bool lap, int dtype, void *const *h_d_ti
             dim3 grid((P->canvas_w + 255) / 256, (rows + 7) / 8);
 #define LAUNCH_BLK(DT, LAPV, CNV)                                                                               \
     do {                                                                                                        \
-        hipLaunchKernelGGL((k_final_fast<DT, LAPV, CNV>), grid, block, 0, ctx->stream, P->d_fdesc, P->n,          \
+        hipLaunchKernelGGL((k_final_fast<DT, LAPV, CNV>), grid, block, 0, ctx->stream, P->d_tiles, P->d_srcs, P->n, \
                            P->d_arena, P->d_luts, d_canvas, (long long)canvas_stride, d_canvas_f32, P->canvas_w,  \
                            P->row_begin, P->row_end);                                                            \
-        hipLaunchKernelGGL((k_final_edge<DT, LAPV, CNV>), grid, block, 0, ctx->stream, P->d_fdesc, P->n,          \
+        hipLaunchKernelGGL((k_final_edge<DT, LAPV, CNV>), grid, block, 0, ctx->stream, P->d_tiles, P->d_srcs, P->n, \
                            P->d_arena, P->d_luts, d_canvas, (long long)canvas_stride, d_canvas_f32, P->canvas_w,  \
                            P->row_begin, P->row_end);                                                            \
     } while (0)
