@@ -658,6 +658,16 @@ __device__ __forceinline__ bool visit_is_interior(const FinalDesc &D, int lx0, i
 __device__ __forceinline__ void tile_weights(const FinalDesc &D, const float *__restrict__ luts, int lx0, int ly0,
                                              float (&w0)[2][4])
 {
+    // edge distance of the whole 4 x 2 rectangle: beyond the feather width every weight is lut[fw]
+    const int dmin = min(min(ly0, D.h - 2 - ly0), min(lx0, D.w - 4 - lx0));
+    if (dmin >= D.fw) {
+        const float wf = luts[D.lut_off + D.fw];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w0[j][k] = wf;
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -941,6 +951,14 @@ __device__ __forceinline__ void store_pixels(const float (&acc)[2][4][CN], const
                                              float *__restrict__ canvas_f32, int cw, int x0, int y0, int nx, int ny)
 {
     const bool vec_ok = (CN == 3) && nx == 4 && ((cstride & 3) == 0) && ((((size_t)canvas) & 3) == 0);
+    // x / 1.0f == x: where every pixel of the wave has sum-of-weights exactly 1 (single coverage beyond the
+    // feather zone, about half of a grid canvas) the IEEE division sequences are skipped -- wave-uniform branch
+    bool ones = true;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ones = ones && (wacc[j][k] == 1.0f);
+    const bool no_div = __all(ones) != 0;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         if (j >= ny) break;
@@ -950,7 +968,7 @@ __device__ __forceinline__ void store_pixels(const float (&acc)[2][4][CN], const
             const float wv = wacc[j][k] > 1e-6f ? wacc[j][k] : 1e-6f;
 #pragma unroll
             for (int c = 0; c < CN; ++c) {
-                const float v = acc[j][k][c] / wv;
+                const float v = no_div ? acc[j][k][c] : acc[j][k][c] / wv;
                 if (canvas_f32 && k < nx) canvas_f32[((size_t)(y0 + j) * cw + x0 + k) * CN + c] = v;
                 const float cl = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
                 ob[k * CN + c] = (unsigned char)cl;
@@ -991,13 +1009,6 @@ __global__ __launch_bounds__(256, 3) void k_final_fast(const FinalDesc *__restri
     const bool overflow = ncand > FINAL_MAX_CAND;
     const FinalDesc *dl = overflow ? descs : s_desc;
     const int nloop = overflow ? n : ncand;
-    // visit classification first: one border visit sends the whole thread to the edge pass
-    for (int i = 0; i < nloop; ++i) {
-        const int4 r = *(const int4 *)&dl[i];                // x, y, w, h
-        const int lx0 = x0 - r.x, ly0 = y0 - r.y;
-        if (lx0 + nx <= 0 || ly0 + ny <= 0 || lx0 >= r.z || ly0 >= r.w) continue;
-        if (!visit_is_interior<LAP>(dl[i], lx0, ly0, nx, ny)) return;
-    }
     float acc[2][4][CN], wacc[2][4];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -1010,7 +1021,9 @@ __global__ __launch_bounds__(256, 3) void k_final_fast(const FinalDesc *__restri
     for (int i = 0; i < nloop; ++i) {
         const FinalDesc D = dl[i];
         const int lx0 = x0 - D.x, ly0 = y0 - D.y;
-        if (lx0 + 4 <= 0 || ly0 + 2 <= 0 || lx0 >= D.w || ly0 >= D.h) continue;
+        if (lx0 + nx <= 0 || ly0 + ny <= 0 || lx0 >= D.w || ly0 >= D.h) continue;
+        // one border visit sends the whole thread to the edge pass (which recomputes every visit)
+        if (!visit_is_interior<LAP>(D, lx0, ly0, nx, ny)) return;
         const bool xo = (D.x & 1) != 0;                      // x0 is a multiple of 4
         const bool yo = ((row_begin - D.y) & 1) != 0;        // y0 - row_begin is a multiple of 2
         if (!xo && !yo) gather_tile_fast<DT, LAP, CN, false, false>(D, arena, luts, lx0, ly0, acc, wacc);
@@ -1021,10 +1034,11 @@ __global__ __launch_bounds__(256, 3) void k_final_fast(const FinalDesc *__restri
     store_pixels<CN>(acc, wacc, canvas, cstride, canvas_f32, cw, x0, y0, nx, ny);
 }
 
-// Final gather, pass 2: the threads pass 1 left out (a border visit).  Blocks that no tile border crosses
-// return right after the candidate scan.
+// Final gather, pass 2: the threads pass 1 left out (a border visit).  Launched only over the blocks a tile
+// border (or the ragged canvas edge) comes near -- the list is built on the host when the plan is made.
 template <int DT, bool LAP, int CN>
 __global__ __launch_bounds__(256) void k_final_edge(const FinalDesc *__restrict__ descs, int n,
+                                                    const int2 *__restrict__ edge_blocks,
                                                     const float *__restrict__ arena, const float *__restrict__ luts,
                                                     unsigned char *__restrict__ canvas, long long cstride,
                                                     float *__restrict__ canvas_f32, int cw, int row_begin, int row_end)
@@ -1032,10 +1046,11 @@ __global__ __launch_bounds__(256) void k_final_edge(const FinalDesc *__restrict_
     __shared__ int s_cnt;
     __shared__ int s_list[FINAL_MAX_CAND];
     __shared__ FinalDesc s_desc[FINAL_MAX_CAND];
-    const int bx0 = blockIdx.x * 256, by0 = row_begin + blockIdx.y * 8;
+    const int2 bxy = edge_blocks[blockIdx.x];
+    const int bx0 = bxy.x * 256, by0 = row_begin + bxy.y * 8;
     const int ncand = block_candidates(descs, n, bx0, by0, min(bx0 + 256, cw), min(by0 + 8, row_end), &s_cnt, s_list, s_desc);
-    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int y0 = row_begin + (blockIdx.y * 4 + threadIdx.y) * 2;
+    const int x0 = (bxy.x * 64 + threadIdx.x) * 4;
+    const int y0 = row_begin + (bxy.y * 4 + threadIdx.y) * 2;
     if (x0 >= cw || y0 >= row_end) return;
     const int nx = min(4, cw - x0), ny = min(2, row_end - y0);
     const bool overflow = ncand > FINAL_MAX_CAND;
@@ -1813,6 +1828,8 @@ struct sr_blend_plan {
     TileSrc *d_srcs = nullptr;
     FinalDesc *d_fdesc = nullptr;
     std::vector<FinalDesc> fdesc;
+    int2 *d_edge_blocks = nullptr;
+    int n_edge_blocks = 0;
     float *d_luts = nullptr;
     // launch extents per level
     int max_w[SR_MAX_LEVELS] = {0}, max_grows[SR_MAX_LEVELS] = {0}, max_rrows[SR_MAX_LEVELS] = {0};
@@ -2160,6 +2177,7 @@ int sr_blend_plan_destroy(sr_blend_plan *plan)
         if (plan->d_classes) (void)hipFree(plan->d_classes);
         if (plan->d_srcs) (void)hipFree(plan->d_srcs);
         if (plan->d_fdesc) (void)hipFree(plan->d_fdesc);
+        if (plan->d_edge_blocks) (void)hipFree(plan->d_edge_blocks);
         if (plan->d_luts) (void)hipFree(plan->d_luts);
     }
     delete plan;
@@ -2326,6 +2344,42 @@ int sr_blend_plan_create(sr_ctx *ctx, const sr_tile_rect *h_tiles, int n, int cn
         D.g1 = T.nl > 1 ? T.g_off[1] : 0; D.r1 = T.nl > 1 ? T.r_off[1] : 0;
     }
     if ((e = hipMalloc((void **)&P->d_luts, sizeof(float) * P->luts.size())) != hipSuccess) return fail(e, "luts");
+    {
+        // blocks (256 x 8 canvas pixels, origin (0, row_begin)) within 16 px of a tile edge line or on the ragged
+        // right / bottom canvas edge: the only blocks in which a visit can be a border visit
+        const int rows = row_end - row_begin;
+        const int nbx = (canvas_w + 255) / 256, nby = (rows + 7) / 8;
+        std::vector<unsigned char> mark((size_t)std::max(nbx, 1) * std::max(nby, 1), 0);
+        auto mark_rect = [&](long long x0, long long y0, long long x1, long long y1) {   // canvas px, half-open
+            x0 = std::max<long long>(x0, 0); x1 = std::min<long long>(x1, canvas_w);
+            y0 = std::max<long long>(y0, row_begin); y1 = std::min<long long>(y1, row_end);
+            if (x0 >= x1 || y0 >= y1) return;
+            for (long long by = (y0 - row_begin) / 8; by <= (y1 - 1 - row_begin) / 8; ++by)
+                for (long long bx = x0 / 256; bx <= (x1 - 1) / 256; ++bx) mark[(size_t)by * nbx + bx] = 1;
+        };
+        const int M = 16;
+        for (int t = 0; t < n && rows > 0; ++t) {
+            const TileDev &T = P->tiles[t];
+            const long long xa = T.x, xb = (long long)T.x + T.w, ya = T.y, yb = (long long)T.y + T.h;
+            mark_rect(xa - M, ya - M, xa + M, yb + M);
+            mark_rect(xb - M, ya - M, xb + M, yb + M);
+            mark_rect(xa - M, ya - M, xb + M, ya + M);
+            mark_rect(xa - M, yb - M, xb + M, yb + M);
+        }
+        if (rows > 0) {
+            if (canvas_w % 4) mark_rect(canvas_w - 4, row_begin, canvas_w, row_end);
+            if (rows % 2) mark_rect(0, row_end - 2, canvas_w, row_end);
+        }
+        std::vector<int2> eb;
+        for (int by = 0; by < nby; ++by)
+            for (int bx = 0; bx < nbx; ++bx)
+                if (mark[(size_t)by * nbx + bx]) eb.push_back(make_int2(bx, by));
+        P->n_edge_blocks = (int)eb.size();
+        if (!eb.empty()) {
+            if ((e = hipMalloc((void **)&P->d_edge_blocks, sizeof(int2) * eb.size())) != hipSuccess) return fail(e, "edge blocks");
+            if ((e = hipMemcpy(P->d_edge_blocks, eb.data(), sizeof(int2) * eb.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload");
+        }
+    }
     if ((e = hipMemcpyAsync(P->d_tiles, P->tiles.data(), sizeof(TileDev) * n, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e, "upload");
     if ((e = hipMemcpyAsync(P->d_classes, P->classes.data(), sizeof(TileDev) * P->classes.size(), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e, "upload");
     if ((e = hipMemcpyAsync(P->d_luts, P->luts.data(), sizeof(float) * P->luts.size(), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e, "upload");
@@ -2437,9 +2491,10 @@ static int blend_impl(sr_blend_plan *P, bool lap, int dtype, void *const *h_d_ti
         hipLaunchKernelGGL((k_final_fast<DT, LAPV, CNV>), grid, block, 0, ctx->stream, P->d_fdesc, P->n,          \
                            P->d_arena, P->d_luts, d_canvas, (long long)canvas_stride, d_canvas_f32, P->canvas_w,  \
                            P->row_begin, P->row_end);                                                            \
-        hipLaunchKernelGGL((k_final_edge<DT, LAPV, CNV>), grid, block, 0, ctx->stream, P->d_fdesc, P->n,          \
-                           P->d_arena, P->d_luts, d_canvas, (long long)canvas_stride, d_canvas_f32, P->canvas_w,  \
-                           P->row_begin, P->row_end);                                                            \
+        if (P->n_edge_blocks > 0)                                                                               \
+            hipLaunchKernelGGL((k_final_edge<DT, LAPV, CNV>), dim3(P->n_edge_blocks), block, 0, ctx->stream,       \
+                               P->d_fdesc, P->n, P->d_edge_blocks, P->d_arena, P->d_luts, d_canvas,               \
+                               (long long)canvas_stride, d_canvas_f32, P->canvas_w, P->row_begin, P->row_end);   \
     } while (0)
             if (P->cn == 3) {
                 if (lap) { if (dtype == SR_U8) LAUNCH_BLK(SRC_U8, true, 3); else LAUNCH_BLK(SRC_F32, true, 3); }
