@@ -63,7 +63,7 @@ def algorithmic_bytes(geo) -> dict:
     }
 
 
-def cpu_baseline(seed_img: np.ndarray, geo_full, budget_tiles=(2, 2)) -> dict:
+def cpu_baseline(seed_img: np.ndarray, geo_full, budget_tiles=(4, 4)) -> dict:
     """The CPU oracle on a bounded sample: a rows x cols corner of the same tile grid
     (same tile size / overlap / levels), tile extract + Laplacian blend + PSNR + 3 x SSIM."""
     from oracle import oracle_c as oc

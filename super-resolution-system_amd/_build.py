@@ -26,9 +26,11 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-ffp-contract=off", "-fvisibility=hidden", "-fgpu-rdc=0" if False else "-DSR_BUILD",
+           # fp-contract off: the fp32 expressions must round exactly like oracle/sr_oracle.c (bit-exact parity).
+           # no SLP: hipcc's v_pk_*_f32 packing costs more register shuffling than it saves here (measured).
+           "-ffp-contract=off", "-fno-slp-vectorize", "-fvisibility=hidden", "-DSR_BUILD",
            "-I", os.path.join(_ROOT, "include"), "-I", CSRC, "-o", LIB] + SOURCES
-    cmd = [c for c in cmd if c]
+    cmd = [c for c in cmd if c] + os.environ.get("SR_HIPCC_EXTRA", "").split()
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/profiles_<tag>/ (tools/collect_profiles.sh) into the committed summaries:
+    profiles/<round>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary
+    profiles/<round>_traffic.json       per-kernel HBM bytes per launch from FETCH_SIZE / WRITE_SIZE
+    profiles/<round>_bench.json         the bench line of the same build
+FETCH_SIZE on gfx950 under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM): the read side is
+calibrated on k_tile_extract, a pure copy whose byte count is known exactly, and that factor is applied to all kernels.
+usage: tools/summarize_profiles.py <tag> <round-prefix>      e.g.  r01b  r01_b
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag, prefix = sys.argv[1], sys.argv[2]
+src = f"gpurun_out/profiles_{tag}"
+os.makedirs("profiles", exist_ok=True)
+shutil.copy(f"{src}/kernel_stats.csv", f"profiles/{prefix}_kernel_stats.csv")
+bench = json.load(open(f"{src}/bench.json"))
+json.dump(bench, open(f"profiles/{prefix}_bench.json", "w"), indent=1)
+
+
+def counter(name):
+    agg = collections.defaultdict(list)
+    for f in glob.glob(f"{src}/pmc_{name}/*/*_counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == name:
+                agg[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+    return {k: sorted(v)[len(v) // 2] for k, v in agg.items()}      # median per launch
+
+
+fetch, write = counter("FETCH_SIZE"), counter("WRITE_SIZE")
+tile_px, canvas_px = bench["config"]["tile_pixels"], bench["config"]["canvas_pixels"]
+known_read = 3.0 * tile_px                      # k_tile_extract reads exactly the tile pixels once
+cal = known_read / (fetch["k_tile_extract"] * 1024.0) if fetch.get("k_tile_extract") else 2.0
+out = {"unit": "bytes per launch (median)", "fetch_calibration_factor": cal,
+       "note": "read = FETCH_SIZE*1024*factor (factor calibrated on k_tile_extract, a pure copy); write = WRITE_SIZE*1024",
+       "kernels": {}}
+for k in sorted(set(fetch) | set(write)):
+    if not k.startswith("k_"):
+        continue
+    rd, wr = fetch.get(k, 0.0) * 1024.0 * cal, write.get(k, 0.0) * 1024.0
+    out["kernels"][k] = {"read": rd, "write": wr, "total": rd + wr}
+json.dump(out, open(f"profiles/{prefix}_traffic.json", "w"), indent=1)
+print(json.dumps(out, indent=1)[:3000])
