@@ -24,19 +24,21 @@ json.dump(bench, open(f"profiles/{prefix}_bench.json", "w"), indent=1)
 
 
 def counter(name):
+    """-> kernel -> counter total per bench step (sum over the launches of the run / number of steps run)."""
     agg = collections.defaultdict(list)
     for f in glob.glob(f"{src}/pmc_{name}/*/*_counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == name:
                 agg[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
-    return {k: sorted(v)[len(v) // 2] for k, v in agg.items()}      # median per launch
+    steps = max(len(agg.get("k_tile_extract", [])), 1)            # one extract launch per step
+    return {k: sum(v) / steps for k, v in agg.items()}
 
 
 fetch, write = counter("FETCH_SIZE"), counter("WRITE_SIZE")
 tile_px, canvas_px = bench["config"]["tile_pixels"], bench["config"]["canvas_pixels"]
 known_read = 3.0 * tile_px                      # k_tile_extract reads exactly the tile pixels once
 cal = known_read / (fetch["k_tile_extract"] * 1024.0) if fetch.get("k_tile_extract") else 2.0
-out = {"unit": "bytes per launch (median)", "fetch_calibration_factor": cal,
+out = {"unit": "bytes per bench step (all launches of the kernel)", "fetch_calibration_factor": cal,
        "note": "read = FETCH_SIZE*1024*factor (factor calibrated on k_tile_extract, a pure copy); write = WRITE_SIZE*1024",
        "kernels": {}}
 for k in sorted(set(fetch) | set(write)):
