@@ -92,6 +92,8 @@ SIGNATURES = {
     "sr_blend_plan_workspace_bytes": (_i, [_vp, C.POINTER(_sz)]),
     "sr_laplacian_blend": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_i64), _vp, _i64, _vp]),
     "sr_weighted_blend": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_i64), _vp, _i64, _vp]),
+    "sr_blend_pyramids": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_i64), _pi, _i, _i]),
+    "sr_blend_gather": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_i64), _vp, _i64, _vp]),
     "sr_laplacian_fusion_host": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(TileRect), _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "sr_weighted_fusion_host": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(TileRect), _i, _i, _i, _i, _i, _vp, _vp]),
     "sr_feather_merge": (_i, [_vp, C.POINTER(MergeTile), _i, C.POINTER(_vp), C.POINTER(_i64), _i, _vp, _i64, _i, _i]),
@@ -514,6 +516,23 @@ class BlendPlan:
         fn = self.ctx.lib.sr_laplacian_blend if laplacian else self.ctx.lib.sr_weighted_blend
         check(fn(self.handle, dtype, ptrs, st, C.c_void_p(d_canvas), int(canvas_stride),
                  C.c_void_p(d_canvas_f32) if d_canvas_f32 else None))
+
+    def _tile_args(self, d_tiles, strides):
+        return ((C.c_void_p * self.n)(*[C.c_void_p(p) for p in d_tiles]), (C.c_int64 * self.n)(*[int(s) for s in strides]))
+
+    def pyramids(self, d_tiles: Sequence[int], strides: Sequence[int], tile_idx: Sequence[int], first: bool,
+                 dtype: int = SR_U8):
+        """Stage A for the listed tiles (first=True also builds the weight pyramids)."""
+        ptrs, st = self._tile_args(d_tiles, strides)
+        idx = (C.c_int * max(len(tile_idx), 1))(*[int(t) for t in tile_idx])
+        check(self.ctx.lib.sr_blend_pyramids(self.handle, dtype, ptrs, st, idx, len(tile_idx), 1 if first else 0))
+
+    def gather(self, d_tiles: Sequence[int], strides: Sequence[int], d_canvas: int, canvas_stride: int,
+               dtype: int = SR_U8, d_canvas_f32: Optional[int] = None):
+        """Stage B: canvas gather over all tiles."""
+        ptrs, st = self._tile_args(d_tiles, strides)
+        check(self.ctx.lib.sr_blend_gather(self.handle, dtype, ptrs, st, C.c_void_p(d_canvas), int(canvas_stride),
+                                           C.c_void_p(d_canvas_f32) if d_canvas_f32 else None))
 
     def close(self):
         if getattr(self, "handle", None):

@@ -2407,31 +2407,28 @@ int sr_blend_plan_workspace_bytes(const sr_blend_plan *plan, size_t *bytes)
     return SR_OK;
 }
 
-static int blend_impl(sr_blend_plan *P, bool lap, int dtype, void *const *h_d_tiles, const int64_t *h_strides,
-                      uint8_t *d_canvas, int64_t canvas_stride, float *d_canvas_f32)
+static int blend_check_tiles(sr_blend_plan *P, int dtype, void *const *h_d_tiles, const int64_t *h_strides)
 {
-    sr_ctx *ctx = P->ctx;
-    if (!h_d_tiles || !h_strides || !d_canvas) return sr_set_error(SR_ERR_INVALID_ARG, "blend: null argument");
+    if (!h_d_tiles || !h_strides) return sr_set_error(SR_ERR_INVALID_ARG, "blend: null argument");
     if (dtype != SR_U8 && dtype != SR_F32) return sr_set_error(SR_ERR_INVALID_ARG, "blend: dtype must be SR_U8 or SR_F32");
-    if (canvas_stride < (int64_t)P->canvas_w * P->cn) return sr_set_error(SR_ERR_SHAPE, "blend: canvas stride too small");
     const int es = dtype == SR_U8 ? 1 : 4;
-    std::vector<TileSrc> srcs(P->n);
     for (int t = 0; t < P->n; ++t) {
         if (!h_d_tiles[t] && !P->tile_rows[t].empty()) return sr_set_error(SR_ERR_INVALID_ARG, "blend: tile %d pointer is null", t);
         if (h_strides[t] < (int64_t)P->tiles[t].w * P->cn * es) return sr_set_error(SR_ERR_SHAPE, "blend: tile %d stride too small", t);
-        srcs[t].p = h_d_tiles[t];
-        srcs[t].stride = h_strides[t];
     }
-    HIPCHK(upload_small(ctx, P->d_srcs, srcs.data(), sizeof(TileSrc) * P->n));
-    for (int t = 0; t < P->n; ++t) {
-        P->fdesc[t].src = h_d_tiles[t];
-        P->fdesc[t].stride = h_strides[t];
-    }
-    HIPCHK(upload_small(ctx, P->d_fdesc, P->fdesc.data(), sizeof(FinalDesc) * P->n));
+    return SR_OK;
+}
+
+// Stage A of the Laplacian blend: weight pyramids (when `first`) and the down / up chains of the listed tiles.
+// The listed tiles' descriptors are compacted into a scratch table, so kernels are launched over exactly them.
+static int blend_pyramids(sr_blend_plan *P, int dtype, void *const *h_d_tiles, const int64_t *h_strides,
+                          const int *idx, int n_idx, bool first)
+{
+    sr_ctx *ctx = P->ctx;
     const int rows = P->row_end - P->row_begin;
-    if (rows <= 0) return SR_OK;
+    if (rows <= 0 || P->max_nl <= 1) return SR_OK;
     dim3 block(64, 4);
-    if (lap && P->max_nl > 1) {
+    if (first) {
         // weight pyramids: level 0 analytic (LUT) -> 1, then planar chain
         for (int i = 0; i + 1 < P->max_nl; ++i) {
             if (P->cmax_rows[i + 1] <= 0) continue;
@@ -2440,48 +2437,106 @@ static int blend_impl(sr_blend_plan *P, bool lap, int dtype, void *const *h_d_ti
             if (i == 0) hipLaunchKernelGGL(k_down<SRC_LUT>, grid, block, 0, ctx->stream, P->d_classes, (const TileSrc *)nullptr, i, 1, P->d_arena, P->d_luts);
             else hipLaunchKernelGGL(k_down<SRC_PLANAR>, grid, block, 0, ctx->stream, P->d_classes, (const TileSrc *)nullptr, i, 1, P->d_arena, P->d_luts);
         }
-        // Gaussian chain of every tile
-        for (int i = 0; i + 1 < P->max_nl; ++i) {
-            if (P->max_grows[i + 1] <= 0) continue;
-            ProfScope ps(ctx, i == 0 ? "down_l0" : "down_l1p");
-            const bool blk = (P->cn == 3 || P->cn == 1) && !(i == 0 && dtype != SR_U8);
-            if (blk) {
-                dim3 grid((P->max_w[i + 1] + 255) / 256, (P->max_grows[i + 1] + 7) / 8, P->n);
-                if (i == 0) {
-                    if (P->cn == 3) hipLaunchKernelGGL((k_down_blk<SRC_U8, 3>), grid, block, 0, ctx->stream, P->d_tiles, P->d_srcs, i, P->d_arena, P->d_luts);
-                    else hipLaunchKernelGGL((k_down_blk<SRC_U8, 1>), grid, block, 0, ctx->stream, P->d_tiles, P->d_srcs, i, P->d_arena, P->d_luts);
-                } else {
-                    if (P->cn == 3) hipLaunchKernelGGL((k_down_blk<SRC_PLANAR, 3>), grid, block, 0, ctx->stream, P->d_tiles, P->d_srcs, i, P->d_arena, P->d_luts);
-                    else hipLaunchKernelGGL((k_down_blk<SRC_PLANAR, 1>), grid, block, 0, ctx->stream, P->d_tiles, P->d_srcs, i, P->d_arena, P->d_luts);
-                }
-                continue;
-            }
-            dim3 grid((P->max_w[i + 1] + 63) / 64, (P->max_grows[i + 1] + 3) / 4, P->n);
-            if (i == 0) {
-                if (dtype == SR_U8) hipLaunchKernelGGL(k_down<SRC_U8>, grid, block, 0, ctx->stream, P->d_tiles, P->d_srcs, i, P->cn, P->d_arena, P->d_luts);
-                else hipLaunchKernelGGL(k_down<SRC_F32>, grid, block, 0, ctx->stream, P->d_tiles, P->d_srcs, i, P->cn, P->d_arena, P->d_luts);
-            } else {
-                hipLaunchKernelGGL(k_down<SRC_PLANAR>, grid, block, 0, ctx->stream, P->d_tiles, P->d_srcs, i, P->cn, P->d_arena, P->d_luts);
-            }
-        }
-        int rc = check_launch("down chain");
-        if (rc) return rc;
-        // collapse chain: levels max_nl-1 .. 1
-        for (int i = P->max_nl - 1; i >= 1; --i) {
-            if (P->max_rrows[i] <= 0) continue;
-            ProfScope ps(ctx, "up_level");
-            if (P->cn == 3 || P->cn == 1) {
-                dim3 grid((P->max_w[i] + 255) / 256, (P->max_rrows[i] + 7) / 8, P->n);
-                if (P->cn == 3) hipLaunchKernelGGL(k_up_level_blk<3>, grid, block, 0, ctx->stream, P->d_tiles, i, P->d_arena);
-                else hipLaunchKernelGGL(k_up_level_blk<1>, grid, block, 0, ctx->stream, P->d_tiles, i, P->d_arena);
-            } else {
-                dim3 grid((P->max_w[i] + 63) / 64, (P->max_rrows[i] + 3) / 4, P->n);
-                hipLaunchKernelGGL(k_up_level, grid, block, 0, ctx->stream, P->d_tiles, i, P->cn, P->d_arena);
-            }
-        }
-        rc = check_launch("up chain");
-        if (rc) return rc;
     }
+    if (n_idx <= 0) return check_launch("weight chain");
+    // compacted tables for this subset (the full tables when the subset is everything, in order)
+    const TileDev *d_tiles = P->d_tiles;
+    const TileSrc *d_srcs = P->d_srcs;
+    std::vector<TileDev> sub_t;
+    std::vector<TileSrc> sub_s(n_idx);
+    bool all = (n_idx == P->n);
+    for (int k = 0; k < n_idx && all; ++k) all = idx[k] == k;
+    for (int k = 0; k < n_idx; ++k) {
+        const int t = idx[k];
+        if (t < 0 || t >= P->n) return sr_set_error(SR_ERR_INVALID_ARG, "blend: tile index %d out of range", t);
+        sub_s[k].p = h_d_tiles[t];
+        sub_s[k].stride = h_strides[t];
+    }
+    int max_w[SR_MAX_LEVELS] = {0}, max_g[SR_MAX_LEVELS] = {0}, max_r[SR_MAX_LEVELS] = {0}, max_nl = 1;
+    for (int k = 0; k < n_idx; ++k) {
+        const TileDev &T = P->tiles[idx[k]];
+        max_nl = std::max(max_nl, T.nl);
+        for (int i = 0; i < T.nl; ++i) {
+            max_w[i] = std::max(max_w[i], T.W[i]);
+            max_g[i] = std::max(max_g[i], T.g1[i] - T.g0[i]);
+            max_r[i] = std::max(max_r[i], T.r1[i] - T.r0[i]);
+        }
+    }
+    if (all) {
+        HIPCHK(upload_small(ctx, P->d_srcs, sub_s.data(), sizeof(TileSrc) * n_idx));
+    } else {
+        sub_t.resize(n_idx);
+        for (int k = 0; k < n_idx; ++k) sub_t[k] = P->tiles[idx[k]];
+        auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+        void *scr = nullptr;
+        int rc = ctx_scratch(ctx, al(sizeof(TileDev) * n_idx) + al(sizeof(TileSrc) * n_idx), &scr);
+        if (rc) return rc;
+        HIPCHK(upload_small(ctx, scr, sub_t.data(), sizeof(TileDev) * n_idx));
+        HIPCHK(upload_small(ctx, (char *)scr + al(sizeof(TileDev) * n_idx), sub_s.data(), sizeof(TileSrc) * n_idx));
+        d_tiles = (const TileDev *)scr;
+        d_srcs = (const TileSrc *)((char *)scr + al(sizeof(TileDev) * n_idx));
+    }
+    // Gaussian chain
+    for (int i = 0; i + 1 < max_nl; ++i) {
+        if (max_g[i + 1] <= 0) continue;
+        ProfScope ps(ctx, i == 0 ? "down_l0" : "down_l1p");
+        const bool blk = (P->cn == 3 || P->cn == 1) && !(i == 0 && dtype != SR_U8);
+        if (blk) {
+            dim3 grid((max_w[i + 1] + 255) / 256, (max_g[i + 1] + 7) / 8, n_idx);
+            if (i == 0) {
+                if (P->cn == 3) hipLaunchKernelGGL((k_down_blk<SRC_U8, 3>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, P->d_arena, P->d_luts);
+                else hipLaunchKernelGGL((k_down_blk<SRC_U8, 1>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, P->d_arena, P->d_luts);
+            } else {
+                if (P->cn == 3) hipLaunchKernelGGL((k_down_blk<SRC_PLANAR, 3>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, P->d_arena, P->d_luts);
+                else hipLaunchKernelGGL((k_down_blk<SRC_PLANAR, 1>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, P->d_arena, P->d_luts);
+            }
+            continue;
+        }
+        dim3 grid((max_w[i + 1] + 63) / 64, (max_g[i + 1] + 3) / 4, n_idx);
+        if (i == 0) {
+            if (dtype == SR_U8) hipLaunchKernelGGL(k_down<SRC_U8>, grid, block, 0, ctx->stream, d_tiles, d_srcs, i, P->cn, P->d_arena, P->d_luts);
+            else hipLaunchKernelGGL(k_down<SRC_F32>, grid, block, 0, ctx->stream, d_tiles, d_srcs, i, P->cn, P->d_arena, P->d_luts);
+        } else {
+            hipLaunchKernelGGL(k_down<SRC_PLANAR>, grid, block, 0, ctx->stream, d_tiles, d_srcs, i, P->cn, P->d_arena, P->d_luts);
+        }
+    }
+    int rc = check_launch("down chain");
+    if (rc) return rc;
+    // collapse chain: levels max_nl-1 .. 1
+    for (int i = max_nl - 1; i >= 1; --i) {
+        if (max_r[i] <= 0) continue;
+        ProfScope ps(ctx, "up_level");
+        if (P->cn == 3 || P->cn == 1) {
+            dim3 grid((max_w[i] + 255) / 256, (max_r[i] + 7) / 8, n_idx);
+            if (P->cn == 3) hipLaunchKernelGGL(k_up_level_blk<3>, grid, block, 0, ctx->stream, d_tiles, i, P->d_arena);
+            else hipLaunchKernelGGL(k_up_level_blk<1>, grid, block, 0, ctx->stream, d_tiles, i, P->d_arena);
+        } else {
+            dim3 grid((max_w[i] + 63) / 64, (max_r[i] + 3) / 4, n_idx);
+            hipLaunchKernelGGL(k_up_level, grid, block, 0, ctx->stream, d_tiles, i, P->cn, P->d_arena);
+        }
+    }
+    return check_launch("up chain");
+}
+
+// Stage B: the canvas gather over all tiles (LAP: from G_1 / R_1 of stage A; else plain weighted average).
+static int blend_gather(sr_blend_plan *P, bool lap, int dtype, void *const *h_d_tiles, const int64_t *h_strides,
+                        uint8_t *d_canvas, int64_t canvas_stride, float *d_canvas_f32)
+{
+    sr_ctx *ctx = P->ctx;
+    if (!d_canvas) return sr_set_error(SR_ERR_INVALID_ARG, "blend: null canvas");
+    if (canvas_stride < (int64_t)P->canvas_w * P->cn) return sr_set_error(SR_ERR_SHAPE, "blend: canvas stride too small");
+    const int rows = P->row_end - P->row_begin;
+    if (rows <= 0) return SR_OK;
+    std::vector<TileSrc> srcs(P->n);
+    for (int t = 0; t < P->n; ++t) {
+        srcs[t].p = h_d_tiles[t];
+        srcs[t].stride = h_strides[t];
+        P->fdesc[t].src = h_d_tiles[t];
+        P->fdesc[t].stride = h_strides[t];
+    }
+    HIPCHK(upload_small(ctx, P->d_srcs, srcs.data(), sizeof(TileSrc) * P->n));
+    HIPCHK(upload_small(ctx, P->d_fdesc, P->fdesc.data(), sizeof(FinalDesc) * P->n));
+    dim3 block(64, 4);
     {
         ProfScope ps(ctx, lap ? "final_gather" : "weighted_gather");
         if (P->cn == 3 || P->cn == 1) {
@@ -2521,6 +2576,41 @@ static int blend_impl(sr_blend_plan *P, bool lap, int dtype, void *const *h_d_ti
         }
     }
     return check_launch("final gather");
+}
+
+static int blend_impl(sr_blend_plan *P, bool lap, int dtype, void *const *h_d_tiles, const int64_t *h_strides,
+                      uint8_t *d_canvas, int64_t canvas_stride, float *d_canvas_f32)
+{
+    int rc = blend_check_tiles(P, dtype, h_d_tiles, h_strides);
+    if (rc) return rc;
+    if (lap) {
+        std::vector<int> idx(P->n);
+        for (int t = 0; t < P->n; ++t) idx[t] = t;
+        rc = blend_pyramids(P, dtype, h_d_tiles, h_strides, idx.data(), P->n, true);
+        if (rc) return rc;
+    }
+    return blend_gather(P, lap, dtype, h_d_tiles, h_strides, d_canvas, canvas_stride, d_canvas_f32);
+}
+
+int sr_blend_pyramids(sr_blend_plan *plan, int dtype, void *const *h_d_tiles, const int64_t *h_strides,
+                      const int *h_tile_idx, int n_idx, int first)
+{
+    if (!plan_is_live(plan)) return sr_set_error(SR_ERR_INVALID_ARG, "sr_blend_pyramids: null or destroyed plan");
+    CTX_ENTER(plan->ctx);
+    if (n_idx < 0 || (n_idx > 0 && !h_tile_idx)) return sr_set_error(SR_ERR_INVALID_ARG, "sr_blend_pyramids: bad tile list");
+    int rc = blend_check_tiles(plan, dtype, h_d_tiles, h_strides);
+    if (rc) return rc;
+    return blend_pyramids(plan, dtype, h_d_tiles, h_strides, h_tile_idx, n_idx, first != 0);
+}
+
+int sr_blend_gather(sr_blend_plan *plan, int dtype, void *const *h_d_tiles, const int64_t *h_strides,
+                    uint8_t *d_canvas, int64_t canvas_stride, float *d_canvas_f32)
+{
+    if (!plan_is_live(plan)) return sr_set_error(SR_ERR_INVALID_ARG, "sr_blend_gather: null or destroyed plan");
+    CTX_ENTER(plan->ctx);
+    int rc = blend_check_tiles(plan, dtype, h_d_tiles, h_strides);
+    if (rc) return rc;
+    return blend_gather(plan, true, dtype, h_d_tiles, h_strides, d_canvas, canvas_stride, d_canvas_f32);
 }
 
 int sr_laplacian_blend(sr_blend_plan *plan, int dtype, void *const *h_d_tiles, const int64_t *h_strides,

@@ -68,18 +68,63 @@ def workload_geometry(name: str) -> Geometry:
 # ---------------------------------------------------------------------------------------------
 # strip partition + exchange plan (host only; runs identically on every rank)
 # ---------------------------------------------------------------------------------------------
-def strip_bounds(canvas_h: int, world: int) -> List[int]:
-    return [canvas_h * r // world for r in range(world + 1)]
+def strip_bounds(canvas_h: int, world: int, geo: Optional["Geometry"] = None, qa_weight: float = 1.1) -> List[int]:
+    """Strip boundaries.  Without a geometry: equal row counts.  With one: equal *work* -- a canvas row costs the
+    tile pixels covering it (pyramid + gather work; rows inside tile overlaps count twice) plus qa_weight x canvas
+    width for the metrics, so strips through overlap zones get fewer rows.  Boundaries are even (the kernels pair
+    rows) and deterministic on every rank."""
+    if world <= 1 or geo is None:
+        return [canvas_h * r // world for r in range(world + 1)]
+    cost = np.full(canvas_h, qa_weight * geo.canvas_w, dtype=np.float64)
+    for (_, y, w, h) in geo.rects:
+        cost[max(y, 0):min(y + h, canvas_h)] += w
+    cum = np.concatenate([[0.0], np.cumsum(cost)])
+    bounds = [0]
+    for r in range(1, world):
+        b = int(np.searchsorted(cum, cum[-1] * r / world))
+        b = min(max(b - (b % 2), bounds[-1] + 2), canvas_h)
+        bounds.append(b)
+    bounds.append(canvas_h)
+    return bounds
 
 
-def tile_owners(rects: Sequence[Tuple[int, int, int, int]], bounds: Sequence[int]) -> List[int]:
-    """Locality-aware ownership: the rank whose strip holds the tile's centre row (most of what a
-    strip needs is then already local; only rows across strip borders travel)."""
+def tile_owners(rects: Sequence[Tuple[int, int, int, int]], bounds: Sequence[int], policy: str = "balanced",
+                need: Optional[List[List[Tuple[int, int]]]] = None, cn: int = 3) -> List[int]:
+    """Which rank holds each (SR output) tile.
+
+    "balanced" (default): greedy, tile by tile, choose the owner that minimises the busiest rank-to-rank link
+    after the assignment, then the bytes added, then the owner's tile count.  xGMI is point-to-point (7 links per
+    GPU), so what bounds the exchange is the heaviest pair, not the total: with 2 ranks this puts every tile on
+    the strip that needs most of it; with 8 it spreads a tile row over the strips that read it so each strip
+    pulls from several peers in parallel.  Needs ``need`` (rows every rank reads of every tile).
+    "roundrobin": tile t on rank t % world (independent SR workers).
+    "locality": the rank whose strip holds the tile's centre row."""
     world = len(bounds) - 1
+    if policy == "roundrobin" or (policy == "balanced" and need is None):
+        return [t % world for t in range(len(rects))]
+    if policy == "locality":
+        out = []
+        for (_, y, _, h) in rects:
+            c = min(y + h // 2, bounds[-1] - 1)
+            out.append(min(max(bisect.bisect_right(bounds, c) - 1, 0), world - 1))
+        return out
+    link = np.zeros((world, world), dtype=np.int64)          # bytes owner -> reader
+    owned = [0] * world
     out = []
-    for (_, y, _, h) in rects:
-        c = min(y + h // 2, bounds[-1] - 1)
-        out.append(min(max(bisect.bisect_right(bounds, c) - 1, 0), world - 1))
+    for t, (_, _, w, _) in enumerate(rects):
+        nbytes = [max(need[r][t][1] - need[r][t][0], 0) * w * cn for r in range(world)]
+        best = None
+        for o in range(world):
+            add = [0 if r == o else nbytes[r] for r in range(world)]
+            worst = max(int(max(link[o, r] + add[r] for r in range(world))), int(link.max()))
+            key = (worst, sum(add), owned[o], o)
+            if best is None or key < best[0]:
+                best = (key, o, add)
+        _, o, add = best
+        for r in range(world):
+            link[o, r] += add[r]
+        owned[o] += 1
+        out.append(o)
     return out
 
 
@@ -113,15 +158,15 @@ class ExchangePlan:
         return sum((b - a) * geo.rects[t][2] * geo.cn for (_, t, a, b) in self.recvs(rank))
 
 
-def make_exchange_plan(geo: Geometry, world: int, halo: int = SSIM_HALO) -> ExchangePlan:
-    bounds = strip_bounds(geo.canvas_h, world)
-    owners = tile_owners(geo.rects, bounds)
+def make_exchange_plan(geo: Geometry, world: int, halo: int = SSIM_HALO, owner_policy: str = "balanced") -> ExchangePlan:
+    bounds = strip_bounds(geo.canvas_h, world, geo)
     rows, need = [], []
     for r in range(world):
         a = max(bounds[r] - (halo if world > 1 else 0), 0)
         b = min(bounds[r + 1] + (halo if world > 1 else 0), geo.canvas_h)
         rows.append((a, b))
         need.append(_native.strip_tile_rows(geo.rects, geo.levels, geo.canvas_h, a, b))
+    owners = tile_owners(geo.rects, bounds, owner_policy, need, geo.cn)
     return ExchangePlan(world, bounds, owners, rows, need)
 
 
@@ -181,6 +226,10 @@ class DevicePipeline:
                                       geo.weight_type, self.row_begin, self.row_end)
         # per-tile (virtual) base pointers and strides for the blend
         self._ptrs, self._strides = [], []
+        self._local_needed = [t for t in range(len(geo.rects))
+                              if self.xplan.need[rank][t][0] < self.xplan.need[rank][t][1] and t in self.local_tiles]
+        self._remote_needed = [t for t in range(len(geo.rects))
+                               if self.xplan.need[rank][t][0] < self.xplan.need[rank][t][1] and t not in self.local_tiles]
         for t, (x, y, w, h) in enumerate(geo.rects):
             stride = w * cn
             a, b = self.xplan.need[rank][t]
@@ -204,13 +253,22 @@ class DevicePipeline:
                               [self.local_tiles[t].stride(0) for t in self.owned])
 
     def stage_exchange(self):
+        """Posts the grouped sends / receives; returns the work handles (empty on one GPU)."""
         if self.world == 1:
-            return
-        for w in exchange_tile_rows(self.xplan, self.rank, self.local_tiles, self.recv_bufs, self.group):
-            w.wait()
+            return []
+        return exchange_tile_rows(self.xplan, self.rank, self.local_tiles, self.recv_bufs, self.group)
 
-    def stage_blend(self):
-        self.plan.blend(self._ptrs, self._strides, self.canvas.data_ptr(), self.canvas.stride(0))
+    def stage_blend(self, pending=()):
+        """Pyramids of the tiles this rank already holds run while the exchange is in flight; the tiles that
+        arrive are processed after the wait, then the canvas gather over all of them."""
+        if not pending:
+            self.plan.blend(self._ptrs, self._strides, self.canvas.data_ptr(), self.canvas.stride(0))
+            return
+        self.plan.pyramids(self._ptrs, self._strides, self._local_needed, first=True)
+        for w in pending:
+            w.wait()
+        self.plan.pyramids(self._ptrs, self._strides, self._remote_needed, first=False)
+        self.plan.gather(self._ptrs, self._strides, self.canvas.data_ptr(), self.canvas.stride(0))
 
     def stage_assess(self, reference):
         """PSNR (exact integer SSE) and the three SSIM variants over this rank's strip, as partial sums left on
@@ -234,8 +292,8 @@ class DevicePipeline:
 
     def step(self, image, reference):
         self.stage_tile(image)
-        self.stage_exchange()
-        self.stage_blend()
+        pending = self.stage_exchange()
+        self.stage_blend(pending)
         self.stage_assess(reference)
         self.stage_reduce()
 

@@ -155,3 +155,32 @@ def test_strip_windows_bit_identical(ctx, rng):
     a, b = plan.tile_rows(0)
     assert 1400 - 160 <= a <= 1400 and 1600 <= b <= 1600 + 160
     plan.close()
+
+
+def test_staged_blend_equals_monolithic(ctx, rng):
+    """sr_blend_pyramids on two disjoint tile subsets + sr_blend_gather == sr_laplacian_blend (the overlap of
+    the multi-GPU row exchange with compute relies on this)."""
+    import _native
+    sizes = [(120, 160), (120, 160), (100, 90), (140, 200), (120, 160)]
+    rects = [(0, 0, 160, 120), (120, 10, 160, 120), (30, 100, 90, 100), (100, 90, 200, 140), (250, 40, 160, 120)]
+    tiles = [_tiles(rng, 1, h, w)[0] for (h, w) in sizes]
+    H, W = 240, 420
+    bufs = [ctx.upload(t) for t in tiles]
+    ptrs, strides = [b.ptr for b in bufs], [t.shape[1] * 3 for t in tiles]
+    plan = _native.BlendPlan(ctx, rects, 3, H, W, 6, "cosine")
+    c1, c2 = ctx.alloc(H * W * 3), ctx.alloc(H * W * 3)
+    plan.blend(ptrs, strides, c1.ptr, W * 3)
+    mono = ctx.download(c1.ptr, (H, W, 3), np.uint8)
+    ref = oc.laplacian_fusion(tiles, [(r[1], r[0]) for r in rects], (H, W), 6, "cosine")
+    assert np.array_equal(mono, ref)
+    plan2 = _native.BlendPlan(ctx, rects, 3, H, W, 6, "cosine")
+    plan2.pyramids(ptrs, strides, [3, 0], first=True)
+    plan2.pyramids(ptrs, strides, [1, 2, 4], first=False)
+    plan2.gather(ptrs, strides, c2.ptr, W * 3)
+    assert np.array_equal(ctx.download(c2.ptr, (H, W, 3), np.uint8), mono)
+    # empty subset is allowed (a rank that owns none of the tiles it needs)
+    plan2.pyramids(ptrs, strides, [], first=True)
+    plan2.pyramids(ptrs, strides, [0, 1, 2, 3, 4], first=False)
+    plan2.gather(ptrs, strides, c2.ptr, W * 3)
+    assert np.array_equal(ctx.download(c2.ptr, (H, W, 3), np.uint8), mono)
+    plan.close(); plan2.close()
