@@ -297,6 +297,22 @@ class DevicePipeline:
         self.stage_assess(reference)
         self.stage_reduce()
 
+    # -- single-process rehearsal of a rank (tests): same buffers, same staged kernels, no communicator ------------
+    def rehearse_fill(self, full_tiles: Dict[int, "object"]):
+        """Put into this rank's buffers exactly what the tile stage + exchange would: its own tiles whole, and of
+        the others only the rows the exchange plan delivers."""
+        for t, buf in self.local_tiles.items():
+            buf.copy_(full_tiles[t])
+        for (_, t, a, b) in self.xplan.recvs(self.rank):
+            self.recv_bufs[t].copy_(full_tiles[t][a:b])
+
+    def rehearse_step(self, reference):
+        """Blend (staged, as with an exchange in flight) + assess, without reduce."""
+        self.plan.pyramids(self._ptrs, self._strides, self._local_needed, first=True)
+        self.plan.pyramids(self._ptrs, self._strides, self._remote_needed, first=False)
+        self.plan.gather(self._ptrs, self._strides, self.canvas.data_ptr(), self.canvas.stride(0))
+        self.stage_assess(reference)
+
     # -- results ----------------------------------------------------------------------------------
     def metrics(self) -> Dict[str, float]:
         """Whole-image scores from the (all-reduced) partial sums; synchronises."""

@@ -247,3 +247,37 @@ def test_full_size_200mp_properties():
     inner = pipe.canvas.view(H, W, 3)[5500:6000, 8000:9300]
     assert int(inner.min()) >= 136 and int(inner.max()) <= 137
     pipe.close()
+
+
+@pytest.mark.parametrize("world", [2, 5, 8])
+def test_virtual_ranks_reproduce_single_gpu(rng, world):
+    """Every rank of an N-GPU run rehearsed on one GPU (its own buffers, only the rows the exchange plan delivers,
+    staged blend): the strips tile the monolithic canvas bit for bit and the partial metric sums add up."""
+    import torch
+    import device_pipeline as dp
+    geo = dp.grid_geometry(tile_w=400, tile_h=330, rows=4, cols=3, ov_x=90)
+    H, W = geo.canvas_h, geo.canvas_w
+    image, reference = _img(rng, H, W), _img(rng, H, W)
+    t_img = torch.from_numpy(image.reshape(H, -1)).cuda()
+    t_ref = torch.from_numpy(reference.reshape(H, -1)).cuda()
+    mono = dp.DevicePipeline(geo, 0, 1, 0)
+    mono.step(t_img, t_ref)
+    torch.cuda.synchronize()
+    want_canvas = mono.canvas.clone()
+    want_sums = mono.results.clone()
+    full_tiles = {t: mono.local_tiles[t].clone() for t in range(len(geo.rects))}
+    got = torch.zeros_like(want_canvas)
+    sums = torch.zeros_like(want_sums)
+    for r in range(world):
+        p = dp.DevicePipeline(geo, r, world, 0)
+        p.rehearse_fill(full_tiles)
+        p.rehearse_step(t_ref)
+        torch.cuda.synchronize()
+        a, b = p.strip
+        got[a:b] = p.canvas[a:b]
+        sums += p.results
+        p.close()
+    assert torch.equal(got, want_canvas)
+    assert float(sums[0]) == float(want_sums[0])                                   # SSE: exact integers
+    assert torch.allclose(sums[1:], want_sums[1:], rtol=1e-12, atol=0)
+    mono.close()
