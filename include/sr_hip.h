@@ -171,6 +171,13 @@ SR_API int sr_weighted_blend(sr_blend_plan *plan, int dtype, void *const *h_d_ti
                              const int64_t *h_strides, uint8_t *d_canvas, int64_t canvas_stride,
                              float *d_canvas_f32);
 
+/* weighted_average_fusion with caller-supplied weight maps (blending_module.py:729-751): h_d_weights[i] is an
+ * h_i x w_i fp32 map in HBM (row stride in bytes).  Same accumulate / normalise / clip / truncate. */
+SR_API int sr_weighted_blend_custom(sr_blend_plan *plan, int dtype, void *const *h_d_tiles,
+                                    const int64_t *h_strides, const float *const *h_d_weights,
+                                    const int64_t *h_weight_strides, uint8_t *d_canvas, int64_t canvas_stride,
+                                    float *d_canvas_f32);
+
 /* Host-buffer conveniences with the reference's call shape (ndarrays in, ndarray out):
  * stage tiles to HBM, blend, copy the canvas back.  h_tiles[i] is a dense HWC array. */
 SR_API int sr_laplacian_fusion_host(sr_ctx *ctx, int dtype, const void *const *h_tiles,
@@ -203,6 +210,10 @@ SR_API int sr_sse_u8(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const ui
 SR_API int sr_sse_u8_async(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uint8_t *d_b,
                            int64_t stride_b, int h, int64_t rowlen, uint64_t *d_sse);
 SR_API double sr_psnr_from_sse(uint64_t sse, uint64_t count, double data_range);
+/* fp32 images (calculate_psnr on float arrays with max > 1, quality_assessment_module.py:191-195 leaves them float):
+ * skimage semantics, fp32 difference and square, fp64 sum.  PSNR = 10 log10(data_range^2 / (sse / count)). */
+SR_API int sr_sse_f32(sr_ctx *ctx, const float *d_a, int64_t stride_a, const float *d_b, int64_t stride_b,
+                      int h, int64_t rowlen, double *h_sse);
 
 /* SSIM between two u8 images of h x w pixels with cn channels (cn == 3: RGB -> gray with the
  * OpenCV fixed-point rule, gray_shift 15 or 14; cn == 1: already gray).  The SSIM map is

@@ -100,6 +100,8 @@ SIGNATURES = {
     "sr_sse_u8": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i64, C.POINTER(C.c_uint64)]),
     "sr_sse_u8_async": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i64, _vp]),
     "sr_psnr_from_sse": (_dbl, [C.c_uint64, C.c_uint64, _dbl]),
+    "sr_sse_f32": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i64, C.POINTER(_dbl)]),
+    "sr_weighted_blend_custom": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_i64), C.POINTER(_vp), C.POINTER(_i64), _vp, _i64, _vp]),
     "sr_ssim_u8": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _dbl, _i, _i, C.POINTER(_dbl), C.POINTER(C.c_uint64)]),
     "sr_ssim_u8_async": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _dbl, _i, _i, _vp, C.POINTER(C.c_uint64)]),
     "sr_assess_u8_async": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _dbl, _i, _i, _i, _vp]),
@@ -351,6 +353,11 @@ class Context:
                                  C.byref(out)))
         return out.value
 
+    def sse_f32(self, d_a: int, stride_a: int, d_b: int, stride_b: int, h: int, rowlen: int) -> float:
+        out = C.c_double(0.0)
+        check(self.lib.sr_sse_f32(self.handle, C.c_void_p(d_a), stride_a, C.c_void_p(d_b), stride_b, h, rowlen, C.byref(out)))
+        return out.value
+
     def sse_u8_async(self, d_a, stride_a, d_b, stride_b, h, rowlen, d_out: int):
         check(self.lib.sr_sse_u8_async(self.handle, C.c_void_p(d_a), stride_a, C.c_void_p(d_b), stride_b, h, rowlen,
                                        C.c_void_p(d_out)))
@@ -516,6 +523,14 @@ class BlendPlan:
         fn = self.ctx.lib.sr_laplacian_blend if laplacian else self.ctx.lib.sr_weighted_blend
         check(fn(self.handle, dtype, ptrs, st, C.c_void_p(d_canvas), int(canvas_stride),
                  C.c_void_p(d_canvas_f32) if d_canvas_f32 else None))
+
+    def blend_custom_weights(self, d_tiles, strides, d_weights, weight_strides, d_canvas: int, canvas_stride: int,
+                             dtype: int = SR_U8, d_canvas_f32: Optional[int] = None):
+        ptrs, st = self._tile_args(d_tiles, strides)
+        wp = (C.c_void_p * self.n)(*[C.c_void_p(p) for p in d_weights])
+        ws = (C.c_int64 * self.n)(*[int(s) for s in weight_strides])
+        check(self.ctx.lib.sr_weighted_blend_custom(self.handle, dtype, ptrs, st, wp, ws, C.c_void_p(d_canvas),
+                                                    int(canvas_stride), C.c_void_p(d_canvas_f32) if d_canvas_f32 else None))
 
     def _tile_args(self, d_tiles, strides):
         return ((C.c_void_p * self.n)(*[C.c_void_p(p) for p in d_tiles]), (C.c_int64 * self.n)(*[int(s) for s in strides]))

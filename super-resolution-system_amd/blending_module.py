@@ -197,10 +197,39 @@ class BlendingModule:
                                 weight_type: WeightType = WeightType.COSINE,
                                 output_shape: Optional[Tuple[int, int]] = None) -> np.ndarray:
         """Distance-weighted average (blending_module.py:661-760)."""
-        if weights is not None and len(weights) > 0:
-            raise NotImplementedError("caller-supplied weight maps are not wired to the HIP path yet")
         images, positions, shape = self._collect(tiles, output_shape, guess_without_shape=True)
-        return self._fuse(images, positions, shape, _weight_name(weight_type), laplacian=False)
+        if weights is None or len(weights) == 0:
+            return self._fuse(images, positions, shape, _weight_name(weight_type), laplacian=False)
+        # caller-supplied maps for the first len(weights) tiles, generated ones for the rest (blending_module.py:729-734)
+        maps = []
+        for i, im in enumerate(images):
+            if i < len(weights):
+                wm = np.ascontiguousarray(np.asarray(weights[i]).squeeze(), dtype=np.float32)
+                if wm.shape != im.shape[:2]:
+                    raise ValueError(f"weight map {i} has shape {wm.shape}, tile is {im.shape[:2]}")
+            else:
+                wm = self._create_distance_weight_map(im.shape[0], im.shape[1], weight_type)
+            maps.append(wm)
+        ctx = self._ctx()
+        is_u8 = all(im.dtype == np.uint8 for im in images)
+        arrs = [np.ascontiguousarray(im if is_u8 else im.astype(np.float32)) for im in images]
+        cn = arrs[0].shape[2] if arrs[0].ndim == 3 else 1
+        es = 1 if is_u8 else 4
+        rects = [(int(p[1]), int(p[0]), a.shape[1], a.shape[0]) for a, p in zip(arrs, positions)]
+        plan = _native.BlendPlan(ctx, rects, cn, shape[0], shape[1], 1, "linear")
+        tb = [ctx.upload(a) for a in arrs]
+        wb = [ctx.upload(m) for m in maps]
+        canvas = ctx.alloc(shape[0] * shape[1] * cn)
+        try:
+            plan.blend_custom_weights([b.ptr for b in tb], [a.shape[1] * cn * es for a in arrs], [b.ptr for b in wb],
+                                      [m.shape[1] * 4 for m in maps], canvas.ptr, shape[1] * cn,
+                                      _native.SR_U8 if is_u8 else _native.SR_F32)
+            return ctx.download(canvas.ptr, (shape[0], shape[1]) if cn == 1 else (shape[0], shape[1], cn), np.uint8)
+        finally:
+            ctx.sync()
+            plan.close()
+            for b in tb + wb + [canvas]:
+                b.free()
 
     def multi_band_fusion(self, tiles, num_bands: int = 6, output_shape: Optional[Tuple[int, int]] = None) -> np.ndarray:
         """blending_module.py:1245-1270: laplacian_fusion with sigmoid weights (num_bands is unused there too)."""

@@ -167,6 +167,8 @@ struct ProfScope {
     }
 };
 
+static const double *reduce_partials(sr_ctx *ctx, const double *part, long long n, int ncomp, double *buf0, double *buf1);
+
 static int check_launch(const char *what)
 {
     hipError_t e = hipGetLastError();
@@ -1274,6 +1276,64 @@ __global__ __launch_bounds__(256) void k_sse_rows(const unsigned char *__restric
     if (lane == 0) ws[wid] = s;
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(out, ws[0] + ws[1] + ws[2] + ws[3]);
+}
+
+// squared differences of two fp32 images (skimage's PSNR on float input: fp32 difference and square, fp64 mean)
+__global__ __launch_bounds__(256) void k_sse_f32(const float *__restrict__ a, long long sa, const float *__restrict__ b,
+                                                 long long sb, int h, long long rowlen, double *__restrict__ part)
+{
+    double s = 0.0;
+    for (int y = blockIdx.y; y < h; y += gridDim.y) {
+        const float *pa = (const float *)((const char *)a + (size_t)y * sa);
+        const float *pb = (const float *)((const char *)b + (size_t)y * sb);
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < rowlen; i += (long long)gridDim.x * blockDim.x) {
+            const float d = pa[i] - pb[i];
+            s += (double)(d * d);
+        }
+    }
+    s = wave_sum_f64(s);
+    __shared__ double ws[4];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = ((ws[0] + ws[1]) + ws[2]) + ws[3];
+}
+
+// weighted_average_fusion with caller-supplied weight maps (blending_module.py:729-751): thread per canvas pixel
+struct CustomW {
+    const float *w;      // h x w fp32 weight map of the tile, row stride in bytes
+    long long stride;
+};
+template <int DT>
+__global__ __launch_bounds__(256) void k_weighted_custom(const TileDev *__restrict__ tiles, const TileSrc *__restrict__ srcs,
+                                                         const CustomW *__restrict__ wts, int n, int cn,
+                                                         unsigned char *__restrict__ canvas, long long cstride,
+                                                         float *__restrict__ canvas_f32, int cw, int row_begin, int row_end)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = row_begin + blockIdx.y * 4 + threadIdx.y;
+    if (x >= cw || y >= row_end) return;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float wacc = 0.f;
+    for (int t = 0; t < n; ++t) {
+        const TileDev &T = tiles[t];
+        const int lx = x - T.x, ly = y - T.y;
+        if (lx < 0 || ly < 0 || lx >= T.w || ly >= T.h) continue;
+        const float w0 = ((const float *)((const char *)wts[t].w + (size_t)ly * wts[t].stride))[lx];
+        const char *srow = (const char *)srcs[t].p + (size_t)ly * srcs[t].stride;
+        for (int c = 0; c < cn; ++c) {
+            const float g0 = DT == SRC_U8 ? (float)((const unsigned char *)srow)[lx * cn + c] : ((const float *)srow)[lx * cn + c];
+            acc[c] += g0 * w0;
+        }
+        wacc += w0;
+    }
+    const float wv = wacc > 1e-6f ? wacc : 1e-6f;
+    unsigned char *o = canvas + (size_t)y * cstride + (size_t)x * cn;
+    for (int c = 0; c < cn; ++c) {
+        const float v = acc[c] / wv;
+        if (canvas_f32) canvas_f32[((size_t)y * cw + x) * cn + c] = v;
+        const float cl = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
+        o[c] = (unsigned char)cl;
+    }
 }
 
 __device__ __forceinline__ int gray_of(const unsigned char *__restrict__ p, int cn, int shift)
@@ -2778,6 +2838,69 @@ int sr_sse_u8_async(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uin
         }
     }
     return check_launch("psnr_sse");
+}
+
+int sr_sse_f32(sr_ctx *ctx, const float *d_a, int64_t stride_a, const float *d_b, int64_t stride_b, int h,
+               int64_t rowlen, double *h_sse)
+{
+    CTX_ENTER(ctx);
+    if (!d_a || !d_b || !h_sse || h < 0 || rowlen < 0) return sr_set_error(SR_ERR_INVALID_ARG, "sr_sse_f32: bad arguments");
+    *h_sse = 0.0;
+    if (h == 0 || rowlen == 0) return SR_OK;
+    const int gx = (int)std::min<int64_t>((rowlen + 255) / 256, 64), gy = std::min(h, 1024);
+    void *scr = nullptr;
+    int rc = ctx_scratch(ctx, (size_t)8 << 20, &scr);
+    if (rc) return rc;
+    double *part = (double *)scr, *r0 = part + (size_t)gx * gy + 32, *r1 = r0 + 4096;
+    {
+        ProfScope ps(ctx, "psnr_sse_f32");
+        hipLaunchKernelGGL(k_sse_f32, dim3(gx, gy), dim3(256), 0, ctx->stream, d_a, (long long)stride_a, d_b, (long long)stride_b,
+                           h, (long long)rowlen, part);
+    }
+    const double *res = reduce_partials(ctx, part, (long long)gx * gy, 1, r0, r1);
+    rc = check_launch("psnr_sse_f32");
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(h_sse, res, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(stream_sync(ctx));
+    return SR_OK;
+}
+
+int sr_weighted_blend_custom(sr_blend_plan *plan, int dtype, void *const *h_d_tiles, const int64_t *h_strides,
+                             const float *const *h_d_weights, const int64_t *h_weight_strides, uint8_t *d_canvas,
+                             int64_t canvas_stride, float *d_canvas_f32)
+{
+    if (!plan_is_live(plan)) return sr_set_error(SR_ERR_INVALID_ARG, "sr_weighted_blend_custom: null or destroyed plan");
+    CTX_ENTER(plan->ctx);
+    sr_blend_plan *P = plan;
+    sr_ctx *c = P->ctx;
+    int rc = blend_check_tiles(P, dtype, h_d_tiles, h_strides);
+    if (rc) return rc;
+    if (!h_d_weights || !h_weight_strides || !d_canvas) return sr_set_error(SR_ERR_INVALID_ARG, "sr_weighted_blend_custom: null argument");
+    if (canvas_stride < (int64_t)P->canvas_w * P->cn) return sr_set_error(SR_ERR_SHAPE, "sr_weighted_blend_custom: canvas stride too small");
+    std::vector<TileSrc> srcs(P->n);
+    std::vector<CustomW> wts(P->n);
+    for (int t = 0; t < P->n; ++t) {
+        if (!h_d_weights[t]) return sr_set_error(SR_ERR_INVALID_ARG, "sr_weighted_blend_custom: weight map %d is null", t);
+        if (h_weight_strides[t] < (int64_t)P->tiles[t].w * 4) return sr_set_error(SR_ERR_SHAPE, "sr_weighted_blend_custom: weight map %d stride too small", t);
+        srcs[t].p = h_d_tiles[t];
+        srcs[t].stride = h_strides[t];
+        wts[t].w = h_d_weights[t];
+        wts[t].stride = h_weight_strides[t];
+    }
+    const int rows = P->row_end - P->row_begin;
+    if (rows <= 0) return SR_OK;
+    void *scr = nullptr;
+    rc = ctx_scratch(c, sizeof(CustomW) * P->n + 256, &scr);
+    if (rc) return rc;
+    HIPCHK(upload_small(c, P->d_srcs, srcs.data(), sizeof(TileSrc) * P->n));
+    HIPCHK(upload_small(c, scr, wts.data(), sizeof(CustomW) * P->n));
+    {
+        ProfScope ps(c, "weighted_custom");
+        dim3 grid((P->canvas_w + 63) / 64, (rows + 3) / 4), block(64, 4);
+        if (dtype == SR_U8) hipLaunchKernelGGL(k_weighted_custom<SRC_U8>, grid, block, 0, c->stream, P->d_tiles, P->d_srcs, (const CustomW *)scr, P->n, P->cn, d_canvas, (long long)canvas_stride, d_canvas_f32, P->canvas_w, P->row_begin, P->row_end);
+        else hipLaunchKernelGGL(k_weighted_custom<SRC_F32>, grid, block, 0, c->stream, P->d_tiles, P->d_srcs, (const CustomW *)scr, P->n, P->cn, d_canvas, (long long)canvas_stride, d_canvas_f32, P->canvas_w, P->row_begin, P->row_end);
+    }
+    return check_launch("weighted_custom");
 }
 
 int sr_sse_u8(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uint8_t *d_b, int64_t stride_b, int h,

@@ -192,6 +192,21 @@ class QualityAssessmentModule:
         return a, b
 
     def calculate_psnr(self, img1: np.ndarray, img2: np.ndarray, data_range: float = 255.0) -> float:
+        p1, p2 = self._preprocess_image(img1), self._preprocess_image(img2)
+        if p1.dtype != np.uint8 or p2.dtype != np.uint8:
+            # float images with max > 1 stay float in the reference: skimage promotes to >= fp32 and averages in fp64
+            a32, b32 = self._crop_pair(np.asarray(p1), np.asarray(p2))
+            a32 = np.ascontiguousarray(a32, dtype=np.float32)
+            b32 = np.ascontiguousarray(b32, dtype=np.float32)
+            ctx = self._ctx()
+            da, db = ctx.upload(a32), ctx.upload(b32)
+            try:
+                rowlen = a32.size // a32.shape[0]
+                sse = ctx.sse_f32(da.ptr, rowlen * 4, db.ptr, rowlen * 4, a32.shape[0], rowlen)
+            finally:
+                da.free(); db.free()
+            mse = sse / a32.size
+            return float("inf") if mse == 0 else float(10 * np.log10((data_range ** 2) / mse))
         a, b = self._pair(img1, img2, "calculate_psnr")
         ctx = self._ctx()
         da, db = _DevImage(ctx, a), _DevImage(ctx, b)

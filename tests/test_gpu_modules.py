@@ -36,6 +36,11 @@ def test_blending_module_surface(rng):
     # bare arrays + output_shape: ceil(sqrt(n)) grid without overlap (blending_module.py:411-416)
     bare = b.laplacian_fusion(tiles, output_shape=(256, 320))
     assert np.array_equal(bare, oc.laplacian_fusion(tiles, [(0, 0), (0, 160), (128, 0), (128, 160)], (256, 320), 6, "cosine"))
+    # caller-supplied weight maps for the first tiles, generated ones for the rest (blending_module.py:729-734)
+    wts = [rng.uniform(0.1, 1.0, (128, 160)).astype(np.float32) for _ in range(2)]
+    got = b.weighted_average_fusion(infos, weights=wts, weight_type=bm.WeightType.COSINE)
+    full_w = wts + [onp.distance_weight_map(128, 160, "cosine")] * 2
+    assert np.array_equal(got, onp.weighted_average_fusion(tiles, pos, (216, 280), "cosine", weights=full_w))
     # pyramids
     img = tiles[0].astype(np.float32)
     gp = b.build_gaussian_pyramid(tiles[0])
@@ -122,6 +127,9 @@ def test_quality_module_surface(rng):
     # float images in [0,1] are rescaled to u8 first
     assert q.calculate_psnr(original / 255.0, upscaled) == oc.psnr((original / 255.0 * 255).astype(np.uint8), upscaled)
     assert np.array_equal(q.downsample_bicubic(a, 0.4), oc.resize_cubic_u8(a, int(120 * 0.4), int(90 * 0.4)))
+    # float images with max > 1 stay float (no rescale): skimage's fp32 difference / fp64 mean
+    fa, fb = a.astype(np.float32) * 0.9 + 3.0, b[:90, :110].astype(np.float64) * 1.01
+    assert q.calculate_psnr(fa, fb) == pytest.approx(onp.psnr(fa[:90, :110], fb.astype(np.float32)), rel=1e-6)
     m = q.evaluate_full_reference(original, upscaled, scale_factor=4)
     ref = onp.downsample_comparison(original, upscaled)
     for k, v in ref.items():
