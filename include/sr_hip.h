@@ -189,6 +189,21 @@ SR_API int sr_weighted_fusion_host(sr_ctx *ctx, int dtype, const void *const *h_
                                    int canvas_w, int weight_type, uint8_t *h_canvas,
                                    float *h_canvas_f32);
 
+/* ---- BlendingModule.detect_seams window scan (blending_module.py:765-903) -------------
+ * For every tile, windows of `window` x `window` pixels every `stride` pixels over the part of the tile inside the
+ * canvas; global-statistics SSIM (fp64) between the tile and the canvas window on gray values (the reference's
+ * BGR2GRAY-on-RGB quirk included).  Windows scoring below `threshold` are returned unordered (up to cap records;
+ * *h_count is the number found -- call again with a larger buffer if it exceeds cap).  Merging adjacent windows into
+ * Seam boxes is host bookkeeping (blending_module.py:905-967). */
+typedef struct sr_seam_record {
+    int tile, x, y, pad;     /* tile index, canvas position of the window */
+    double score;
+} sr_seam_record;
+SR_API int sr_seam_scan(sr_ctx *ctx, const uint8_t *d_canvas, int64_t canvas_stride, int canvas_h, int canvas_w,
+                        int cn, const sr_tile_rect *h_rects, void *const *h_d_tiles, const int64_t *h_strides,
+                        int n, int window, int stride, int gray_shift, double threshold, sr_seam_record *h_out,
+                        int cap, int *h_count);
+
 /* ---- TilingModule.merge_tiles feather path (tiling_module.py:1074-1175) ---------------- */
 typedef struct sr_merge_tile {
     int x, y;                 /* int(global_x*scale), int(global_y*scale)                 */

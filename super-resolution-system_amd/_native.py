@@ -39,6 +39,10 @@ class MergeTile(C.Structure):
                                         "ov_t", "ov_b", "ov_l", "ov_r")]
 
 
+class SeamRecord(C.Structure):
+    _fields_ = [("tile", C.c_int), ("x", C.c_int), ("y", C.c_int), ("pad", C.c_int), ("score", C.c_double)]
+
+
 class AssessSums(C.Structure):
     _fields_ = [("sse", C.c_double), ("ssim_uniform", C.c_double), ("ssim_gauss", C.c_double),
                 ("ssim_simple", C.c_double)]
@@ -100,6 +104,8 @@ SIGNATURES = {
     "sr_sse_u8": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i64, C.POINTER(C.c_uint64)]),
     "sr_sse_u8_async": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i64, _vp]),
     "sr_psnr_from_sse": (_dbl, [C.c_uint64, C.c_uint64, _dbl]),
+    "sr_seam_scan": (_i, [_vp, _vp, _i64, _i, _i, _i, C.POINTER(TileRect), C.POINTER(_vp), C.POINTER(_i64), _i, _i, _i, _i,
+                          _dbl, C.POINTER(SeamRecord), _i, _pi]),
     "sr_sse_f32": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i64, C.POINTER(_dbl)]),
     "sr_weighted_blend_custom": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_i64), C.POINTER(_vp), C.POINTER(_i64), _vp, _i64, _vp]),
     "sr_ssim_u8": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _dbl, _i, _i, C.POINTER(_dbl), C.POINTER(C.c_uint64)]),
@@ -352,6 +358,27 @@ class Context:
         check(self.lib.sr_sse_u8(self.handle, C.c_void_p(d_a), stride_a, C.c_void_p(d_b), stride_b, h, rowlen,
                                  C.byref(out)))
         return out.value
+
+    def seam_scan(self, d_canvas: int, canvas_stride: int, canvas_h: int, canvas_w: int, cn: int, rects_xywh,
+                  d_tiles: Sequence[int], strides: Sequence[int], window: int, stride: int, threshold: float,
+                  gray_shift: int = 15):
+        """-> [(tile, x, y, score)] of the windows below threshold, sorted by (tile, y, x)."""
+        n = len(rects_xywh)
+        rects = (TileRect * n)(*[TileRect(int(x), int(y), int(w), int(h)) for (x, y, w, h) in rects_xywh])
+        ptrs = (C.c_void_p * n)(*[C.c_void_p(p) for p in d_tiles])
+        st = (C.c_int64 * n)(*[int(s) for s in strides])
+        cap = 1 << 16
+        while True:
+            recs = (SeamRecord * cap)()
+            cnt = C.c_int(0)
+            check(self.lib.sr_seam_scan(self.handle, C.c_void_p(d_canvas), canvas_stride, canvas_h, canvas_w, cn, rects,
+                                        ptrs, st, n, window, stride, gray_shift, threshold, recs, cap, C.byref(cnt)))
+            if cnt.value <= cap:
+                break
+            cap = cnt.value
+        out = [(recs[i].tile, recs[i].x, recs[i].y, recs[i].score) for i in range(cnt.value)]
+        out.sort(key=lambda r: (r[0], r[2], r[1]))
+        return out
 
     def sse_f32(self, d_a: int, stride_a: int, d_b: int, stride_b: int, h: int, rowlen: int) -> float:
         out = C.c_double(0.0)

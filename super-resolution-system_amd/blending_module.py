@@ -6,8 +6,8 @@ blend hot path (reference blending_module.py:38-56,96-136,164-363,369-561,661-76
 (include/sr_hip.h) -- there is no NumPy/OpenCV compute path here and no CPU fallback: without
 libsrhip.so or a GPU the compute methods raise.
 
-Out of scope for this path: Poisson / gradient-domain fusion, seam detect/repair,
-colour correction, feather_blend's distance transform.  Those methods exist so callers get a clear
+Out of scope for this path: Poisson / gradient-domain fusion, seam repair, colour
+correction, feather_blend's distance transform.  detect_seams is built.  Those methods exist so callers get a clear
 NotImplementedError instead of an AttributeError.
 
 Reference quirks kept: bare arrays without output_shape fail like the
@@ -261,8 +261,65 @@ class BlendingModule:
     def gradient_domain_fusion(self, *a, **k):
         self._out_of_scope("gradient_domain_fusion")
 
-    def detect_seams(self, *a, **k):
-        self._out_of_scope("detect_seams")
+    def detect_seams(self, result: np.ndarray, tiles: List[Union[np.ndarray, TileInfo]], window_size: int = 16,
+                     stride: int = 8) -> List[Seam]:
+        """Windowed SSIM between the fused canvas and every source tile (blending_module.py:765-853); the window
+        scan runs on the GPU (sr_seam_scan), grouping of adjacent hits follows :905-967 on the host."""
+        result = np.ascontiguousarray(result)
+        if result.dtype != np.uint8:
+            raise NotImplementedError("detect_seams: uint8 canvas only")
+        infos = [t if isinstance(t, TileInfo) else TileInfo(np.asarray(t), 0, 0, 0, 0) for t in tiles]
+        cn = result.shape[2] if result.ndim == 3 else 1
+        keep = []
+        for ti in infos:
+            img = np.asarray(ti.image)
+            if img.dtype != np.uint8:
+                raise NotImplementedError("detect_seams: uint8 tiles only")
+            if (img.ndim == 3) != (result.ndim == 3) or (img.ndim == 3 and img.shape[2] != cn):
+                continue                                  # result_roi.shape != tile_roi.shape -> skipped by the reference
+            keep.append((np.ascontiguousarray(img), int(ti.x), int(ti.y)))
+        if not keep:
+            return []
+        ctx = self._ctx()
+        d_res = ctx.upload(result)
+        bufs = [ctx.upload(img) for (img, _, _) in keep]
+        try:
+            hits = ctx.seam_scan(d_res.ptr, result.shape[1] * cn, result.shape[0], result.shape[1], cn,
+                                 [(x, y, img.shape[1], img.shape[0]) for (img, x, y) in keep], [b.ptr for b in bufs],
+                                 [img.shape[1] * cn for (img, _, _) in keep], window_size, stride, self.ssim_threshold)
+        finally:
+            ctx.sync()
+            d_res.free()
+            for b in bufs:
+                b.free()
+        seams = [Seam(x=x, y=y, width=window_size, height=window_size, ssim_score=score) for (_, x, y, score) in hits]
+        return self._merge_adjacent_seams(seams, distance_threshold=window_size)
+
+    def _merge_adjacent_seams(self, seams: List[Seam], distance_threshold: int = 16) -> List[Seam]:
+        """Group consecutive hits (sorted by y, then x) closer than the threshold; a group becomes its bounding box
+        with the mean score (blending_module.py:905-967)."""
+        if not seams:
+            return []
+        ordered = sorted(seams, key=lambda s: (s.y, s.x))
+        groups, cur = [], [ordered[0]]
+        for s in ordered[1:]:
+            last = cur[-1]
+            if np.sqrt((s.x - last.x) ** 2 + (s.y - last.y) ** 2) < distance_threshold:
+                cur.append(s)
+            else:
+                groups.append(cur)
+                cur = [s]
+        groups.append(cur)
+        merged = []
+        for g in groups:
+            if len(g) == 1:
+                merged.append(g[0])
+                continue
+            x0, y0 = min(s.x for s in g), min(s.y for s in g)
+            x1, y1 = max(s.x + s.width for s in g), max(s.y + s.height for s in g)
+            merged.append(Seam(x=x0, y=y0, width=x1 - x0, height=y1 - y0,
+                               ssim_score=float(np.mean([s.ssim_score for s in g]))))
+        return merged
 
     def repair_seams(self, *a, **k):
         self._out_of_scope("repair_seams")

@@ -1278,6 +1278,71 @@ __global__ __launch_bounds__(256) void k_sse_rows(const unsigned char *__restric
     if (threadIdx.x == 0) atomicAdd(out, ws[0] + ws[1] + ws[2] + ws[3]);
 }
 
+__device__ __forceinline__ int gray_rgb(int r, int g, int b, int shift)
+{
+    return shift == 15 ? (r * 9798 + g * 19235 + b * 3735 + (1 << 14)) >> 15
+                       : (r * 4899 + g * 9617 + b * 1868 + (1 << 13)) >> 14;
+}
+
+// detect_seams (blending_module.py:765-853): one thread = one window of one tile.  Gray values (BGR2GRAY applied to
+// RGB data, i.e. swapped R/B weights, as the reference does) are integers, so the five window sums are exact; the
+// global-statistics SSIM of the window is finished in fp64 and windows below the threshold are appended.
+struct SeamTile {
+    const unsigned char *p;
+    long long stride;
+    int x, y, w, h;          // canvas position, size
+    int roi_w, roi_h;        // part inside the canvas
+    int nwx, nwy;            // windows per row / column
+    long long first;         // index of this tile's first window in the flat window numbering
+};
+struct SeamRec {
+    int tile, x, y, pad;
+    double score;
+};
+
+__global__ __launch_bounds__(256) void k_seam_scan(const unsigned char *__restrict__ canvas, long long cstride, int cn,
+                                                   const SeamTile *__restrict__ tiles, int ntiles, long long nwin,
+                                                   int window, int stride, int shift, double threshold, double c1,
+                                                   double c2, SeamRec *__restrict__ out, int cap, int *__restrict__ count)
+{
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= nwin) return;
+    int t = 0;
+    while (t + 1 < ntiles && tiles[t + 1].first <= gid) ++t;
+    const SeamTile T = tiles[t];
+    const long long local = gid - T.first;
+    const int wy = (int)(local / T.nwx), wx = (int)(local - (long long)wy * T.nwx);
+    const int x0 = wx * stride, y0 = wy * stride;
+    long long sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+    for (int r = 0; r < window; ++r) {
+        const unsigned char *pt = T.p + (size_t)(y0 + r) * T.stride + (size_t)x0 * cn;
+        const unsigned char *pc = canvas + (size_t)(T.y + y0 + r) * cstride + (size_t)(T.x + x0) * cn;
+        for (int c = 0; c < window; ++c) {
+            int a, b;
+            if (cn == 1) {
+                a = pt[c];
+                b = pc[c];
+            } else {      // BGR2GRAY on RGB data: first channel gets the blue weight
+                a = gray_rgb(pt[3 * c + 2], pt[3 * c + 1], pt[3 * c], shift);
+                b = gray_rgb(pc[3 * c + 2], pc[3 * c + 1], pc[3 * c], shift);
+            }
+            sx += a; sy += b; sxx += a * a; syy += b * b; sxy += a * b;
+        }
+    }
+    const double n = (double)window * (double)window;
+    const double mu1 = (double)sx / n, mu2 = (double)sy / n;
+    const double s1 = (double)sxx / n - mu1 * mu1, s2 = (double)syy / n - mu2 * mu2, s12 = (double)sxy / n - mu1 * mu2;
+    const double score = ((2 * mu1 * mu2 + c1) * (2 * s12 + c2)) / ((mu1 * mu1 + mu2 * mu2 + c1) * (s1 + s2 + c2));
+    if (score < threshold) {
+        const int k = atomicAdd(count, 1);
+        if (k < cap) {
+            SeamRec rec;
+            rec.tile = t; rec.x = T.x + x0; rec.y = T.y + y0; rec.pad = 0; rec.score = score;
+            out[k] = rec;
+        }
+    }
+}
+
 // squared differences of two fp32 images (skimage's PSNR on float input: fp32 difference and square, fp64 mean)
 __global__ __launch_bounds__(256) void k_sse_f32(const float *__restrict__ a, long long sa, const float *__restrict__ b,
                                                  long long sb, int h, long long rowlen, double *__restrict__ part)
@@ -1413,12 +1478,6 @@ __device__ __forceinline__ void load_gray_pair(const unsigned char *__restrict__
     }
 }
 
-
-__device__ __forceinline__ int gray_rgb(int r, int g, int b, int shift)
-{
-    return shift == 15 ? (r * 9798 + g * 19235 + b * 3735 + (1 << 14)) >> 15
-                       : (r * 4899 + g * 9617 + b * 1868 + (1 << 13)) >> 14;
-}
 
 // Gray halo tile of both images into LDS, four pixels per thread step (one 12-byte load per image for RGB,
 // one 4-byte load for gray input); groups that leave the image take the per-pixel REFLECT_101 path.
@@ -2838,6 +2897,67 @@ int sr_sse_u8_async(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uin
         }
     }
     return check_launch("psnr_sse");
+}
+
+int sr_seam_scan(sr_ctx *ctx, const uint8_t *d_canvas, int64_t canvas_stride, int canvas_h, int canvas_w, int cn,
+                 const sr_tile_rect *h_rects, void *const *h_d_tiles, const int64_t *h_strides, int n, int window,
+                 int stride, int gray_shift, double threshold, sr_seam_record *h_out, int cap, int *h_count)
+{
+    CTX_ENTER(ctx);
+    if (!d_canvas || !h_rects || !h_d_tiles || !h_strides || !h_count || n < 0 || (cap > 0 && !h_out))
+        return sr_set_error(SR_ERR_INVALID_ARG, "sr_seam_scan: null argument");
+    if ((cn != 1 && cn != 3) || window < 1 || stride < 1 || (gray_shift != 14 && gray_shift != 15))
+        return sr_set_error(SR_ERR_INVALID_ARG, "sr_seam_scan: bad channel count / window / stride / gray_shift");
+    *h_count = 0;
+    std::vector<SeamTile> st;
+    long long nwin = 0;
+    for (int t = 0; t < n; ++t) {
+        const sr_tile_rect &r = h_rects[t];
+        if (r.x < 0 || r.y < 0 || r.w < 1 || r.h < 1 || !h_d_tiles[t]) return sr_set_error(SR_ERR_INVALID_ARG, "sr_seam_scan: bad tile %d", t);
+        SeamTile T;
+        T.p = (const unsigned char *)h_d_tiles[t];
+        T.stride = h_strides[t];
+        T.x = r.x; T.y = r.y; T.w = r.w; T.h = r.h;
+        T.roi_w = std::min(r.x + r.w, canvas_w) - r.x;
+        T.roi_h = std::min(r.y + r.h, canvas_h) - r.y;
+        T.nwx = T.roi_w >= window ? (T.roi_w - window) / stride + 1 : 0;
+        T.nwy = T.roi_h >= window ? (T.roi_h - window) / stride + 1 : 0;
+        if (T.roi_w <= 0 || T.roi_h <= 0) T.nwx = T.nwy = 0;
+        T.first = nwin;
+        nwin += (long long)T.nwx * T.nwy;
+        st.push_back(T);
+    }
+    if (nwin == 0) return SR_OK;
+    const size_t b_tiles = (sizeof(SeamTile) * st.size() + 255) / 256 * 256;
+    const size_t b_out = sizeof(SeamRec) * (size_t)std::max(cap, 1);
+    void *scr = nullptr;
+    int rc = ctx_scratch(ctx, b_tiles + b_out + 512, &scr);
+    if (rc) return rc;
+    SeamTile *d_t = (SeamTile *)scr;
+    int *d_cnt = (int *)((char *)scr + b_tiles);
+    SeamRec *d_out = (SeamRec *)((char *)scr + b_tiles + 256);
+    HIPCHK(upload_small(ctx, d_t, st.data(), sizeof(SeamTile) * st.size()));
+    HIPCHK(hipMemsetAsync(d_cnt, 0, sizeof(int), ctx->stream));
+    {
+        ProfScope ps(ctx, "seam_scan");
+        const long long blocks = (nwin + 255) / 256;
+        hipLaunchKernelGGL(k_seam_scan, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_canvas, (long long)canvas_stride, cn,
+                           (const SeamTile *)d_t, (int)st.size(), nwin, window, stride, gray_shift, threshold,
+                           (0.01 * 255.0) * (0.01 * 255.0), (0.03 * 255.0) * (0.03 * 255.0), d_out, cap, d_cnt);
+    }
+    rc = check_launch("seam_scan");
+    if (rc) return rc;
+    int cnt = 0;
+    HIPCHK(hipMemcpyAsync(&cnt, d_cnt, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(stream_sync(ctx));
+    *h_count = cnt;
+    const int ncopy = std::min(cnt, cap);
+    if (ncopy > 0) {
+        static_assert(sizeof(SeamRec) == sizeof(sr_seam_record), "record layouts must match");
+        HIPCHK(hipMemcpyAsync(h_out, d_out, sizeof(SeamRec) * (size_t)ncopy, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(stream_sync(ctx));
+    }
+    return SR_OK;
 }
 
 int sr_sse_f32(sr_ctx *ctx, const float *d_a, int64_t stride_a, const float *d_b, int64_t stride_b, int h,

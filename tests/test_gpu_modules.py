@@ -289,3 +289,26 @@ def test_virtual_ranks_reproduce_single_gpu(rng, world):
     assert float(sums[0]) == float(want_sums[0])                                   # SSE: exact integers
     assert torch.allclose(sums[1:], want_sums[1:], rtol=1e-12, atol=0)
     mono.close()
+
+
+def test_detect_seams(rng):
+    """blending_module.py:765-967: window SSIM scan on the GPU + host merge vs the oracle."""
+    import blending_module as bm
+    tiles = [_img(rng, 96, 120) for _ in range(4)]
+    for i, t in enumerate(tiles):                       # make the tiles disagree so the blend has visible seams
+        t[:] = np.clip(t.astype(np.int16) + 25 * i - 30, 0, 255).astype(np.uint8)
+    infos, _ = bm.create_tile_grid(tiles, (2, 2), overlap=30)
+    b = bm.BlendingModule(num_levels=4, ssim_threshold=0.9)
+    result = b.laplacian_fusion(infos, output_shape=(162, 210))
+    got = b.detect_seams(result, infos, window_size=16, stride=8)
+    want = onp.detect_seams(result, tiles, [(i.x, i.y) for i in infos], 0.9, 16, 8)
+    assert len(got) == len(want) and len(got) > 0
+    for g, w in zip(got, want):
+        assert (g.x, g.y, g.width, g.height) == w[:4]
+        assert g.ssim_score == pytest.approx(w[4], rel=1e-9, abs=1e-12)
+        assert g.severity in ("low", "medium", "high")
+    # nothing below an impossible threshold; bare arrays are scanned at the origin
+    b0 = bm.BlendingModule(ssim_threshold=-2.0)
+    assert b0.detect_seams(result, infos) == []
+    assert len(bm.BlendingModule(ssim_threshold=0.9).detect_seams(result[:96, :120], [tiles[0]])) == \
+        len(onp.detect_seams(result[:96, :120], [tiles[0]], [(0, 0)], 0.9, 16, 8))
