@@ -56,8 +56,7 @@ def algorithmic_bytes(geo) -> dict:
         "down_l1p": (12.0 * s14 + 12.0 * s25) * n,                 # G1..G4 in, G2..G5 out
         "up_level": (34.0 * s14 + 28.0 * 4.0 ** -5) * n,           # G_i, G_i+1/4, R_i+1/4, W_i in; R_i out
         "final_gather": 9.0 * n + 3.0 * m,                         # u8 tile + G1/4 + R1/4 in; u8 canvas out
-        "assess_gauss_sse": 6.0 * m,                               # both u8 images once: SSE + gauss11 + simple
-        "assess_uniform": 6.0 * m,                                 # both u8 images once: uniform-7 (integer)
+        "assess_all": 6.0 * m,                                     # both u8 images once: SSE + 3 SSIM variants (one pass)
         # the reference-shaped model of SURVEY 8(d) (scatter into fp32 accumulators), for comparison
         "_survey_blend_model": 63.30 * n + 19.0 * m,
     }
@@ -66,7 +65,7 @@ def algorithmic_bytes(geo) -> dict:
 # bench kernel family -> rocprofv3 kernel name (profiles/*_traffic.json)
 ROCPROF_NAMES = {"tile_extract": "k_tile_extract", "down_l0": "k_down_blk<0, 3>", "down_l1p": "k_down_blk<2, 3>",
                  "up_level": "k_up_level_blk<3>", "final_gather": ["k_final_fast<0, true, 3>", "k_final_edge<0, true, 3>"],
-                 "assess_gauss_sse": "k_assess_gauss<3>", "assess_uniform": "k_assess_uniform<3>"}
+                 "assess_all": "k_assess_march<3>"}
 
 
 def measured_traffic() -> dict:
@@ -227,7 +226,7 @@ def main() -> int:
                         "traffic_source": traffic.get("_source"),
                         "avg_launch_ms": round(per_launch_ms, 4),
                         "alg_bytes_per_launch": k["alg_GB"] / k["launches_per_step"] * 1e9}
-            if dom == "assess_gauss_sse":
+            if dom == "assess_all":
                 roofline["note"] = ("fp64-VALU-bound: the reference's SSIM is float64; ~126 fp64 ops per pixel put its "
                                     "floor near 0.65 ms at 200 MP, above its 0.2 ms HBM time")
         gpu_ms = sum(v["ms_per_step"] for v in kernels.values())

@@ -1419,31 +1419,17 @@ __global__ __launch_bounds__(256) void k_rgb2gray(const unsigned char *__restric
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fused assessment kernels.
-//
-// k_assess_gauss: one pass over both u8 images (6 B / pixel) producing, per block,
-//   * the sum of squared differences of its interior pixels (PSNR),
-//   * the sum of the Gaussian-11 SSIM map over the cropped (valid) region  -> "gauss"  (branch A)
-//   * the sum of the same map over the full frame with REFLECT_101 borders -> "simple" (branch B)
-// The two SSIM variants share every filtered value: scipy's gaussian_filter(sigma 1.5, truncate 3.5)
-// and cv2.GaussianBlur((11,11), 1.5) are the same normalised kernel, they differ only in border rule
-// and crop.  fp64 throughout (reference numerics); the row pass works on exact integers: gray values,
-// (x+y)^2 and (x-y)^2 are ints, symmetric taps are pair-summed as ints and only 6 products per map are
-// formed.  4 filtered maps (x, y, (x+y)^2, (x-y)^2) replace the reference's 5:
-//   uxx + uyy = (P + Q) / 2,  uxy = (P - Q) / 4.
-//
-// k_assess_uniform: the uniform 7x7 variant entirely in integers (window sums are exact), fp64 only
-// for the final formula.
+// Fused assessment (k_assess_march below): one pass over both u8 images (6 B / pixel) for
+//   * the sum of squared differences (PSNR),
+//   * the Gaussian-11 SSIM map summed over the cropped (valid) region -> "gauss"  (branch A) and over the full
+//     frame with REFLECT_101 borders -> "simple" (branch B): scipy's gaussian_filter(sigma 1.5, truncate 3.5) and
+//     cv2.GaussianBlur((11,11), 1.5) are the same normalised kernel, the variants differ only in border and crop,
+//   * the uniform 7x7 SSIM map, entirely in integers (window sums are exact), fp64 only for the final formula.
+// fp64 throughout where the reference is (float64); the row pass works on exact integers: gray values, (x+y)^2 and
+// (x-y)^2 are ints, symmetric taps are pair-summed as ints and only 6 products per map are formed.  4 filtered maps
+// (x, y, (x+y)^2, (x-y)^2) replace the reference's 5:  uxx + uyy = (P + Q) / 2,  uxy = (P - Q) / 4.
 // ---------------------------------------------------------------------------------------------
-#define AG_TX 32
-#define AG_TY 54
-#define AG_R 5
-#define AG_ROWS (AG_TY + 2 * AG_R) /* 64 */
-#define AG_COLS (AG_TX + 2 * AG_R) /* 42 */
-#define AG_GP 44                   /* gray row pitch (bytes)  */
-#define AG_HP 33                   /* H row pitch (doubles)   */
-
-enum { ASSESS_SSE = 1, ASSESS_UNIFORM = 2, ASSESS_GAUSS = 4, ASSESS_SIMPLE = 8 };
+enum { ASSESS_SSE = 1, ASSESS_UNIFORM = 2, ASSESS_GAUSS = 4, ASSESS_SIMPLE = 8, ASSESS_ALL_BITS = 15 };
 
 struct AssessParams {
     int h, w, shift, ry0, ry1, flags, same_c;
@@ -1557,196 +1543,143 @@ __device__ __forceinline__ double ssim_value(double ux, double uy, double spq, d
     return (a1 * a2) * fast_recip(b1 * b2);
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_assess_march: all four metrics in ONE pass, column-marching.  A block is 256 columns wide (768 B of RGB per
+// row: whole cache lines, ~4 % column halo) and AM_TY rows tall.  After the gray halo tile is in LDS each thread owns
+// one column and walks down the rows: the row pass of its column (integer pair sums, 6 fp64 products per map) goes
+// into an 11-deep register FIFO, the column pass reads the FIFO (static indices: the row loop is unrolled by 11), so
+// the filtered maps never touch LDS and there is no barrier after the load phase.  The uniform-7 variant rides
+// along: its per-row 7-tap integer sums go through a 7-slot per-column ring in LDS, the 7x7 sums slide in registers.
+// ---------------------------------------------------------------------------------------------
+#define AM_TX 256
+#define AM_TY 62
+#define AM_R 5
+#define AM_ROWS (AM_TY + 2 * AM_R) /* 72: gray tile + ring = 53 KB -> 3 blocks per CU */
+#define AM_GP 272                   /* gray row pitch: 68 groups of 4 pixels */
+
 template <int CN>
-__global__ __launch_bounds__(256) void k_assess_gauss(const unsigned char *__restrict__ a, long long sa,
+__global__ __launch_bounds__(256) void k_assess_march(const unsigned char *__restrict__ a, long long sa,
                                                       const unsigned char *__restrict__ b, long long sb,
                                                       AssessParams P, double *__restrict__ part)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char gxs[AG_ROWS][AG_GP];
-    __shared__ __attribute__((aligned(16))) unsigned char gys[AG_ROWS][AG_GP];
-    __shared__ double H[4][AG_ROWS][AG_HP];
-    __shared__ double red[4][3];
-    const int tid = threadIdx.x;
-    const int bx0 = blockIdx.x * AG_TX, by0 = P.ry0 + blockIdx.y * AG_TY;
-    // ---- phase 1: gray halo tile (REFLECT_101 outside the image) + squared differences -----------
-    const unsigned long long sse = load_gray_tile<CN, AG_ROWS, AG_GP / 4, AG_GP, AG_R, AG_TX, AG_TY>(
+    __shared__ __attribute__((aligned(16))) unsigned char gxs[AM_ROWS][AM_GP];
+    __shared__ __attribute__((aligned(16))) unsigned char gys[AM_ROWS][AM_GP];
+    __shared__ int U[7][2][AM_TX];      // per-row 7-tap sums, 62 bits packed: {sx:11, sy:11, sq lo:10}, {sp:21, sq hi:9}
+    __shared__ double red[4][4];
+    const int c = threadIdx.x;
+    const int bx0 = blockIdx.x * AM_TX, by0 = P.ry0 + blockIdx.y * AM_TY;
+    const unsigned long long sse = load_gray_tile<CN, AM_ROWS, AM_GP / 4, AM_GP, AM_R, AM_TX, AM_TY>(
         a, sa, b, sb, P.h, P.w, P.shift, P.ry1, (P.flags & ASSESS_SSE) != 0, bx0, by0, gxs, gys);
     __syncthreads();
-    // ---- phase 2: row pass, thread = (row, 8 output columns) ---------------------------------------
-    {
-        const int row = tid & 63, g = tid >> 6;      // lanes walk rows: H row pitch 33 doubles -> conflict-free writes
-        int xv[18], yv[18], pv[18], qv[18];
+    const int mx = bx0 + c;
+    const bool col_ok = mx < P.w;
+    const bool do_u = (P.flags & ASSESS_UNIFORM) != 0, do_g = (P.flags & (ASSESS_GAUSS | ASSESS_SIMPLE)) != 0;
+    const bool u_col = mx >= 3 && mx < P.w - 3, g_col = mx >= AM_R && mx < P.w - AM_R;
+    double f[4][11];
 #pragma unroll
-        for (int i = 0; i < 18; ++i) {
-            xv[i] = gxs[row][8 * g + i];
-            yv[i] = gys[row][8 * g + i];
-            const int sm = xv[i] + yv[i], df = xv[i] - yv[i];
-            pv[i] = sm * sm;
-            qv[i] = df * df;
-        }
+    for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int o = 0; o < 8; ++o) {
-            const int c = o + AG_R;
-            double hx = (double)xv[c] * P.k[0], hy = (double)yv[c] * P.k[0];
-            double hp = (double)pv[c] * P.k[0], hq = (double)qv[c] * P.k[0];
+        for (int i = 0; i < 11; ++i) f[m][i] = 0.0;
+    int t_xy = 0, t_p = 0, t_q = 0;
+    double sum_int = 0.0, sum_all = 0.0, sum_u = 0.0;
+    const double inv49 = 1.0 / 49.0, cn49 = 49.0 / 48.0;
+#pragma unroll 1
+    for (int base = 0; base < AM_ROWS; base += 11) {
 #pragma unroll
-            for (int j = 1; j <= AG_R; ++j) {
-                hx = fma((double)(xv[c - j] + xv[c + j]), P.k[j], hx);
-                hy = fma((double)(yv[c - j] + yv[c + j]), P.k[j], hy);
-                hp = fma((double)(pv[c - j] + pv[c + j]), P.k[j], hp);
-                hq = fma((double)(qv[c - j] + qv[c + j]), P.k[j], hq);
+        for (int s = 0; s < 11; ++s) {
+            const int r = base + s;
+            if (r < AM_ROWS) {
+            int xv[11], yv[11], pv[11], qv[11];
+#pragma unroll
+            for (int j = 0; j < 11; ++j) {
+                xv[j] = gxs[r][c + j];
+                yv[j] = gys[r][c + j];
+                // Opaque to the optimiser: with the values known to be zero-extended bytes, hipcc (ROCm 7.2) folded sums of
+                // byte products into v_perm_b32 + v_dot4_u32_u8 sequences that gave wrong sums (seen in an earlier kernel)
+                asm volatile("" : "+v"(xv[j]), "+v"(yv[j]));
+                const int sm = xv[j] + yv[j], df = xv[j] - yv[j];
+                pv[j] = sm * sm;
+                qv[j] = df * df;
             }
-            H[0][row][8 * g + o] = hx;
-            H[1][row][8 * g + o] = hy;
-            H[2][row][8 * g + o] = hp;
-            H[3][row][8 * g + o] = hq;
-        }
-    }
-    __syncthreads();
-    // ---- phase 3: column pass + SSIM formula, thread = (column, 7 consecutive rows); each filtered row is read
-    //      from LDS once and slides through registers --------------------------------------------------------------
-    double sum_int = 0.0, sum_all = 0.0;
-    {
-        const int col = tid & 31, rg = tid >> 5;
-        const int mx = bx0 + col;
-        const int orow0 = rg * 7;
-        double u[4][7];
+            if (do_g) {
+                double hx = (double)xv[5] * P.k[0], hy = (double)yv[5] * P.k[0];
+                double hp = (double)pv[5] * P.k[0], hq = (double)qv[5] * P.k[0];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            double hv[17];
-#pragma unroll
-            for (int i = 0; i < 17; ++i) hv[i] = H[m][min(orow0 + i, AG_ROWS - 1)][col];
-#pragma unroll
-            for (int r = 0; r < 7; ++r) {
-                double acc = hv[r + AG_R] * P.k[0];
-#pragma unroll
-                for (int j = 1; j <= AG_R; ++j) acc = fma(hv[r + AG_R - j] + hv[r + AG_R + j], P.k[j], acc);
-                u[m][r] = acc;
+                for (int j = 1; j <= AM_R; ++j) {
+                    hx = fma((double)(xv[5 - j] + xv[5 + j]), P.k[j], hx);
+                    hy = fma((double)(yv[5 - j] + yv[5 + j]), P.k[j], hy);
+                    hp = fma((double)(pv[5 - j] + pv[5 + j]), P.k[j], hp);
+                    hq = fma((double)(qv[5 - j] + qv[5 + j]), P.k[j], hq);
+                }
+                f[0][s] = hx; f[1][s] = hy; f[2][s] = hp; f[3][s] = hq;
             }
-        }
+            if (do_u) {
+                int ux = 0, uy = 0, up = 0, uq = 0;
 #pragma unroll
-        for (int r = 0; r < 7; ++r) {
-            const int orow = orow0 + r;
-            const int my = by0 + orow;
-            if (orow < AG_TY && my < P.ry1 && my < P.h && mx < P.w) {
-                const double spq = 0.5 * (u[2][r] + u[3][r]), dpq = 0.25 * (u[2][r] - u[3][r]);
-                const bool interior = my >= AG_R && my < P.h - AG_R && mx >= AG_R && mx < P.w - AG_R;
-                if (P.same_c) {
-                    const double sv = ssim_value(u[0][r], u[1][r], spq, dpq, P.c1a, P.c2a);
-                    sum_all += sv;
-                    if (interior) sum_int += sv;
-                } else {
-                    if (P.flags & ASSESS_SIMPLE) sum_all += ssim_value(u[0][r], u[1][r], spq, dpq, P.c1b, P.c2b);
-                    if (interior && (P.flags & ASSESS_GAUSS)) sum_int += ssim_value(u[0][r], u[1][r], spq, dpq, P.c1a, P.c2a);
+                for (int j = 2; j <= 8; ++j) { ux += xv[j]; uy += yv[j]; up += pv[j]; uq += qv[j]; }
+                const int slot = r % 7;
+                if (r >= 7) {
+                    const unsigned o0 = (unsigned)U[slot][0][c], o1 = (unsigned)U[slot][1][c];
+                    t_xy -= (int)((o0 & 0x7FFu) | (((o0 >> 11) & 0x7FFu) << 16));
+                    t_p -= (int)(o1 & 0x1FFFFFu);
+                    t_q -= (int)((o0 >> 22) | ((o1 >> 21) << 10));
+                }
+                t_xy += ux | (uy << 16); t_p += up; t_q += uq;
+                U[slot][0][c] = (int)((unsigned)ux | ((unsigned)uy << 11) | (((unsigned)uq & 0x3FFu) << 22));
+                U[slot][1][c] = (int)((unsigned)up | (((unsigned)uq >> 10) << 21));
+                const int orow = r - 8, my = by0 + orow;             // window rows r-6 .. r, centre r-3
+                if (orow >= 0 && orow < AM_TY && my < P.ry1 && my >= 3 && my < P.h - 3 && u_col) {
+                    const double mux = (double)(t_xy & 0xFFFF) * inv49, muy = (double)((unsigned)t_xy >> 16) * inv49;
+                    const double sxxyy = (double)((t_p + t_q) >> 1) * inv49;     // (sum xx + sum yy) / 49, exact integers
+                    const double sxy = (double)((t_p - t_q) >> 2) * inv49;       // sum xy / 49
+                    const double uxuy = mux * muy, uu = mux * mux + muy * muy;
+                    const double a1 = 2.0 * uxuy + P.c1a, a2 = 2.0 * (cn49 * (sxy - uxuy)) + P.c2a;
+                    const double b1 = uu + P.c1a, b2 = cn49 * (sxxyy - uu) + P.c2a;
+                    sum_u += (a1 * a2) * fast_recip(b1 * b2);
                 }
             }
+            if (do_g && r >= 2 * AM_R) {
+                const int orow = r - 2 * AM_R, my = by0 + orow;      // rows r-10 .. r are in the FIFO, centre r-5
+                if (orow < AM_TY && my < P.ry1 && my < P.h && col_ok) {
+                    double u[4];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        double acc = f[m][(s + 6) % 11] * P.k[0];
+#pragma unroll
+                        for (int j = 1; j <= AM_R; ++j)
+                            acc = fma(f[m][(s + 6 + 11 - j) % 11] + f[m][(s + 6 + j) % 11], P.k[j], acc);
+                        u[m] = acc;
+                    }
+                    const double spq = 0.5 * (u[2] + u[3]), dpq = 0.25 * (u[2] - u[3]);
+                    const bool interior = my >= AM_R && my < P.h - AM_R && g_col;
+                    if (P.same_c) {
+                        const double sv = ssim_value(u[0], u[1], spq, dpq, P.c1a, P.c2a);
+                        sum_all += sv;
+                        if (interior) sum_int += sv;
+                    } else {
+                        if (P.flags & ASSESS_SIMPLE) sum_all += ssim_value(u[0], u[1], spq, dpq, P.c1b, P.c2b);
+                        if (interior && (P.flags & ASSESS_GAUSS)) sum_int += ssim_value(u[0], u[1], spq, dpq, P.c1a, P.c2a);
+                    }
+                }
+            }
+            }
         }
     }
-    // ---- phase 4: block reduction -> part[block][0..2] ---------------------------------------------------
     sum_int = wave_sum_f64(sum_int);
     sum_all = wave_sum_f64(sum_all);
-    double dsse = wave_sum_f64((double)sse);          // per-thread sums are < 2^40: exact in fp64
-    if ((tid & 63) == 0) {
-        red[tid >> 6][0] = sum_int;
-        red[tid >> 6][1] = sum_all;
-        red[tid >> 6][2] = dsse;
+    sum_u = wave_sum_f64(sum_u);
+    const double dsse = wave_sum_f64((double)sse);
+    if ((c & 63) == 0) {
+        red[c >> 6][0] = sum_int;
+        red[c >> 6][1] = sum_all;
+        red[c >> 6][2] = dsse;
+        red[c >> 6][3] = sum_u;
     }
     __syncthreads();
-    if (tid < 3) {
+    if (c < 4) {
         const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-        part[blk * 3 + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+        part[blk * 4 + c] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
     }
-}
-
-#define AU_TX 64
-#define AU_TY 26
-#define AU_R 3
-#define AU_ROWS (AU_TY + 2 * AU_R) /* 32 */
-#define AU_COLS (AU_TX + 2 * AU_R) /* 70 */
-#define AU_GP 76                   /* 19 dwords: odd pitch, rows across lanes read conflict-free */
-
-template <int CN>
-__global__ __launch_bounds__(256) void k_assess_uniform(const unsigned char *__restrict__ a, long long sa,
-                                                        const unsigned char *__restrict__ b, long long sb,
-                                                        AssessParams P, double *__restrict__ part)
-{
-    __shared__ __attribute__((aligned(16))) unsigned char gxs[AU_ROWS][AU_GP];
-    __shared__ __attribute__((aligned(16))) unsigned char gys[AU_ROWS][AU_GP];
-    __shared__ int4 HS[AU_TX][AU_ROWS + 1];      // column-major: lanes walk rows in the row pass, columns in the column pass
-    __shared__ double red[4];
-    const int tid = threadIdx.x;
-    const int bx0 = blockIdx.x * AU_TX, by0 = P.ry0 + blockIdx.y * AU_TY;
-    (void)load_gray_tile<CN, AU_ROWS, 18, AU_GP, AU_R, AU_TX, AU_TY>(a, sa, b, sb, P.h, P.w, P.shift, P.ry1, false, bx0,
-                                                                             by0, gxs, gys);
-    __syncthreads();
-    {   // row pass: sliding 7-tap integer sums, thread = (row, 8 output columns)
-        const int row = tid & 31, g = tid >> 5;
-        int xv[14], yv[14], xx[14], yy[14], xy[14];
-#pragma unroll
-        for (int i = 0; i < 14; ++i) {
-            xv[i] = gxs[row][8 * g + i];
-            yv[i] = gys[row][8 * g + i];
-            // Opaque to the optimiser: with the values known to be zero-extended bytes, hipcc (ROCm 7.2) folds
-            // the sliding sums of products into v_perm_b32 + v_dot4_u32_u8 sequences that give wrong sums.
-            asm volatile("" : "+v"(xv[i]), "+v"(yv[i]));
-            xx[i] = xv[i] * xv[i];
-            yy[i] = yv[i] * yv[i];
-            xy[i] = xv[i] * yv[i];
-        }
-        int sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
-#pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            sx += xv[i]; sy += yv[i];
-            sxx += xx[i]; syy += yy[i]; sxy += xy[i];
-        }
-#pragma unroll
-        for (int o = 0; o < 8; ++o) {
-            HS[8 * g + o][row] = make_int4(sx | (sy << 16), sxx, syy, sxy);
-            if (o < 7) {
-                sx = sx + xv[o + 7] - xv[o];
-                sy = sy + yv[o + 7] - yv[o];
-                sxx = sxx + xx[o + 7] - xx[o];
-                syy = syy + yy[o + 7] - yy[o];
-                sxy = sxy + xy[o + 7] - xy[o];
-            }
-        }
-    }
-    __syncthreads();
-    double sum = 0.0;
-    {   // column pass: sliding 7-row integer sums, thread = (column, 7 consecutive rows)
-        const int col = tid & 63, rg = tid >> 6;
-        const int mx = bx0 + col;
-        const int r_first = rg * 7;
-        int t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-#pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            const int4 v = HS[col][min(r_first + i, AU_ROWS - 1)];
-            t0 += v.x; t1 += v.y; t2 += v.z; t3 += v.w;
-        }
-        const double inv = 1.0 / 49.0, cn = 49.0 / 48.0;
-#pragma unroll 1
-        for (int r = 0; r < 7; ++r) {
-            const int orow = r_first + r;
-            const int my = by0 + orow;
-            if (orow >= AU_TY || my >= P.ry1) break;
-            if (my >= AU_R && my < P.h - AU_R && mx >= AU_R && mx < P.w - AU_R) {
-                const double ux = (double)(t0 & 0xFFFF) * inv, uy = (double)((unsigned)t0 >> 16) * inv;
-                const double uxx = (double)t1 * inv, uyy = (double)t2 * inv, uxy = (double)t3 * inv;
-                const double vx = cn * (uxx - ux * ux), vy = cn * (uyy - uy * uy), vxy = cn * (uxy - ux * uy);
-                const double a1 = 2.0 * ux * uy + P.c1a, a2 = 2.0 * vxy + P.c2a;
-                const double b1 = ux * ux + uy * uy + P.c1a, b2 = vx + vy + P.c2a;
-                sum += (a1 * a2) * fast_recip(b1 * b2);
-            }
-            if (r < 6 && orow + 7 < AU_ROWS) {
-                const int4 vn = HS[col][orow + 7], vo = HS[col][orow];
-                t0 += vn.x - vo.x; t1 += vn.y - vo.y; t2 += vn.z - vo.z; t3 += vn.w - vo.w;
-            }
-        }
-    }
-    sum = wave_sum_f64(sum);
-    if ((tid & 63) == 0) red[tid >> 6] = sum;
-    __syncthreads();
-    if (tid == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
 // Deterministic two-level sum of per-block partials laid out as part[i * ncomp + comp]:
@@ -3113,36 +3046,27 @@ int sr_assess_u8_async(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const 
     P.same_c = (P.c1a == P.c1b && P.c2a == P.c2b) ? 1 : 0;
     gauss_taps(P.k);
     const int rows = row_end - row_begin;
-    const bool need_g = rows > 0 && (flags & (ASSESS_SSE | ASSESS_GAUSS | ASSESS_SIMPLE));
-    const bool need_u = rows > 0 && (flags & ASSESS_UNIFORM);
-    const long long gbx = (w + AG_TX - 1) / AG_TX, gby = (rows + AG_TY - 1) / AG_TY;
-    const long long ubx = (w + AU_TX - 1) / AU_TX, uby = (rows + AU_TY - 1) / AU_TY;
-    const size_t n_g = need_g ? (size_t)(gbx * gby) : 0, n_u = need_u ? (size_t)(ubx * uby) : 0;
-    const size_t red_doubles = ((std::max(n_g, n_u) + 1023) / 1024 + 1) * 3;
-    auto al = [](size_t v) { return (v + 255) / 256 * 256; };
-    const size_t o_part_g = 0, o_part_u = o_part_g + al(n_g * 3 * 8), o_r0 = o_part_u + al(n_u * 8),
-                 o_r1 = o_r0 + al(red_doubles * 8), o_r2 = o_r1 + al(red_doubles * 8), o_r3 = o_r2 + al(red_doubles * 8),
-                 total = o_r3 + al(red_doubles * 8);
-    void *scr = nullptr;
-    int rc = ctx_scratch(ctx, std::max<size_t>(total, (size_t)8 << 20), &scr);
-    if (rc) return rc;
-    char *base = (char *)scr;
-    const double *res_g = nullptr, *res_u = nullptr;
-    if (need_g) {
-        ProfScope ps(ctx, "assess_gauss_sse");
-        double *part = (double *)(base + o_part_g);
-        if (cn == 3) hipLaunchKernelGGL(k_assess_gauss<3>, dim3((unsigned)gbx, (unsigned)gby), dim3(256), 0, ctx->stream, d_a, (long long)stride_a, d_b, (long long)stride_b, P, part);
-        else hipLaunchKernelGGL(k_assess_gauss<1>, dim3((unsigned)gbx, (unsigned)gby), dim3(256), 0, ctx->stream, d_a, (long long)stride_a, d_b, (long long)stride_b, P, part);
-        res_g = reduce_partials(ctx, part, (long long)n_g, 3, (double *)(base + o_r0), (double *)(base + o_r1));
+    const double *res = nullptr;
+    if (rows > 0 && (flags & ASSESS_ALL_BITS)) {
+        const long long gbx = (w + AM_TX - 1) / AM_TX, gby = (rows + AM_TY - 1) / AM_TY;
+        const size_t nblk = (size_t)(gbx * gby);
+        const size_t red_doubles = ((nblk + 1023) / 1024 + 1) * 4;
+        auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+        const size_t o_part = 0, o_r0 = o_part + al(nblk * 4 * 8), o_r1 = o_r0 + al(red_doubles * 8),
+                     total = o_r1 + al(red_doubles * 8) + 512;
+        void *scr = nullptr;
+        int rc = ctx_scratch(ctx, std::max<size_t>(total, (size_t)8 << 20), &scr);
+        if (rc) return rc;
+        char *base = (char *)scr;
+        double *part = (double *)(base + o_part);
+        {
+            ProfScope ps(ctx, "assess_all");
+            if (cn == 3) hipLaunchKernelGGL(k_assess_march<3>, dim3((unsigned)gbx, (unsigned)gby), dim3(256), 0, ctx->stream, d_a, (long long)stride_a, d_b, (long long)stride_b, P, part);
+            else hipLaunchKernelGGL(k_assess_march<1>, dim3((unsigned)gbx, (unsigned)gby), dim3(256), 0, ctx->stream, d_a, (long long)stride_a, d_b, (long long)stride_b, P, part);
+            res = reduce_partials(ctx, part, (long long)nblk, 4, (double *)(base + o_r0), (double *)(base + o_r1));
+        }
     }
-    if (need_u) {
-        ProfScope ps(ctx, "assess_uniform");
-        double *part = (double *)(base + o_part_u);
-        if (cn == 3) hipLaunchKernelGGL(k_assess_uniform<3>, dim3((unsigned)ubx, (unsigned)uby), dim3(256), 0, ctx->stream, d_a, (long long)stride_a, d_b, (long long)stride_b, P, part);
-        else hipLaunchKernelGGL(k_assess_uniform<1>, dim3((unsigned)ubx, (unsigned)uby), dim3(256), 0, ctx->stream, d_a, (long long)stride_a, d_b, (long long)stride_b, P, part);
-        res_u = reduce_partials(ctx, part, (long long)n_u, 1, (double *)(base + o_r2), (double *)(base + o_r3));
-    }
-    hipLaunchKernelGGL(k_assess_store, dim3(1), dim3(64), 0, ctx->stream, res_g, res_u, flags, d_out);
+    hipLaunchKernelGGL(k_assess_store, dim3(1), dim3(64), 0, ctx->stream, res, res ? res + 3 : nullptr, flags, d_out);
     return check_launch("assess");
 }
 
