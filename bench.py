@@ -148,11 +148,19 @@ def main() -> int:
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible -- the HIP path has no CPU fallback", file=sys.stderr)
         return 2
+    # SR_DIST_BACKEND=gloo is the single-GPU rehearsal of the multi-rank path (ranks share one card, rows staged
+    # through the host); the measured configuration is always RCCL ("nccl"), one rank per GPU.
+    backend = os.environ.get("SR_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     geo = dp.workload_geometry(args.workload)
     H, W, cn = geo.canvas_h, geo.canvas_w, geo.cn
@@ -194,7 +202,7 @@ def main() -> int:
     prof = {} if args.no_prof else ctx.prof_get()
     ctx.prof_enable(False)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -243,7 +251,7 @@ def main() -> int:
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if backend == "nccl" else f"synthetic (REHEARSAL backend {backend}: not a measurement)",
             "config": {"workload": f"720p->{args.workload} {geo.canvas_w}x{geo.canvas_h} canvas, "
                                    f"{len(geo.rects)} tiles {geo.rects[0][2]}x{geo.rects[0][3]}, {geo.levels}-level "
                                    f"Laplacian blend (cosine weights) + PSNR + SSIM(uniform7,gauss11,simple)",

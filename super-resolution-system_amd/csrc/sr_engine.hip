@@ -618,26 +618,30 @@ __device__ __forceinline__ void up_block_interior(const float *__restrict__ plan
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         const f4_t q = ld_f4_a4(plane + (size_t)(r0 + r) * ps + c0);
+        // power-of-two factors of the odd phases are folded into the final constants (exact; see up_regs)
         if (!XO) {
             h[r][0] = (q.x + q.y * 6.0f) + q.z;
-            h[r][1] = (q.y + q.z) * 4.0f;
+            h[r][1] = q.y + q.z;
             h[r][2] = (q.y + q.z * 6.0f) + q.w;
-            h[r][3] = (q.z + q.w) * 4.0f;
+            h[r][3] = q.z + q.w;
         } else {
-            h[r][0] = (q.x + q.y) * 4.0f;
+            h[r][0] = q.x + q.y;
             h[r][1] = (q.x + q.y * 6.0f) + q.z;
-            h[r][2] = (q.y + q.z) * 4.0f;
+            h[r][2] = q.y + q.z;
             h[r][3] = (q.y + q.z * 6.0f) + q.w;
         }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float ev = ((h[0][k] + h[1][k] * 6.0f) + h[2][k]) * (1.0f / 64.0f);
+        const bool kodd = XO ? ((k & 1) == 0) : ((k & 1) == 1);
+        const float ce = kodd ? (1.0f / 16.0f) : (1.0f / 64.0f);
+        const float co = kodd ? (1.0f / 4.0f) : (1.0f / 16.0f);
+        const float ev = ((h[0][k] + h[1][k] * 6.0f) + h[2][k]) * ce;
         if (!YO) {
             u[0][k] = ev;
-            u[1][k] = ((h[1][k] + h[2][k]) * 4.0f) * (1.0f / 64.0f);
+            u[1][k] = (h[1][k] + h[2][k]) * co;
         } else {
-            u[0][k] = ((h[0][k] + h[1][k]) * 4.0f) * (1.0f / 64.0f);
+            u[0][k] = (h[0][k] + h[1][k]) * co;
             u[1][k] = ev;
         }
     }
@@ -684,29 +688,35 @@ __device__ __forceinline__ void tile_weights(const FinalDesc &D, const float *__
 template <bool XO, bool YO>
 __device__ __forceinline__ void up_regs(const f4_t (&q)[3], float (&u)[2][4])
 {
+    // Scaling by a power of two commutes with fp32 rounding, so the x4 of the odd phases ((a + b) * 4) is not
+    // applied where the reference applies it but folded into the final constant: 1/64 (even,even), 1/16 (one odd
+    // phase), 1/4 (odd,odd).  Bit-identical to the reference order, 10 multiplies fewer per plane.
     float h[3][4];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         if (!XO) {
             h[r][0] = (q[r].x + q[r].y * 6.0f) + q[r].z;
-            h[r][1] = (q[r].y + q[r].z) * 4.0f;
+            h[r][1] = q[r].y + q[r].z;
             h[r][2] = (q[r].y + q[r].z * 6.0f) + q[r].w;
-            h[r][3] = (q[r].z + q[r].w) * 4.0f;
+            h[r][3] = q[r].z + q[r].w;
         } else {
-            h[r][0] = (q[r].x + q[r].y) * 4.0f;
+            h[r][0] = q[r].x + q[r].y;
             h[r][1] = (q[r].x + q[r].y * 6.0f) + q[r].z;
-            h[r][2] = (q[r].y + q[r].z) * 4.0f;
+            h[r][2] = q[r].y + q[r].z;
             h[r][3] = (q[r].y + q[r].z * 6.0f) + q[r].w;
         }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float ev = ((h[0][k] + h[1][k] * 6.0f) + h[2][k]) * (1.0f / 64.0f);
+        const bool kodd = XO ? ((k & 1) == 0) : ((k & 1) == 1);          // pixel k is an odd pyrUp column phase
+        const float ce = kodd ? (1.0f / 16.0f) : (1.0f / 64.0f);          // even row phase
+        const float co = kodd ? (1.0f / 4.0f) : (1.0f / 16.0f);           // odd row phase
+        const float ev = ((h[0][k] + h[1][k] * 6.0f) + h[2][k]) * ce;
         if (!YO) {
             u[0][k] = ev;
-            u[1][k] = ((h[1][k] + h[2][k]) * 4.0f) * (1.0f / 64.0f);
+            u[1][k] = (h[1][k] + h[2][k]) * co;
         } else {
-            u[0][k] = ((h[0][k] + h[1][k]) * 4.0f) * (1.0f / 64.0f);
+            u[0][k] = (h[0][k] + h[1][k]) * co;
             u[1][k] = ev;
         }
     }

@@ -170,20 +170,45 @@ def make_exchange_plan(geo: Geometry, world: int, halo: int = SSIM_HALO, owner_p
     return ExchangePlan(world, bounds, owners, rows, need)
 
 
+class _StagedWork:
+    """Work handle of the host-staged rehearsal exchange: wait() finishes the receive and copies it to the GPU."""
+
+    def __init__(self, work, host=None, dev=None):
+        self.work, self.host, self.dev = work, host, dev
+
+    def wait(self):
+        self.work.wait()
+        if self.dev is not None:
+            self.dev.copy_(self.host)
+
+
 def exchange_tile_rows(plan: ExchangePlan, rank: int, local_tiles: Dict[int, "object"],
                        recv_bufs: Dict[int, "object"], group=None):
     """Send the rows other strips need of the tiles this rank owns, receive the rows this strip
     needs of tiles owned elsewhere.  Tiles are 2-D uint8 tensors [h, w*cn]; recv_bufs[t] has exactly
     (r1 - r0) rows.  One grouped batch of point-to-point ops (ncclSend/ncclRecv under
-    ncclGroupStart/End on RCCL; plain isend/irecv on gloo).  Returns the work handles."""
+    ncclGroupStart/End on RCCL; plain isend/irecv on gloo).  Returns the work handles.
+
+    gloo cannot move device tensors point-to-point: with that backend and GPU tensors (the single-GPU rehearsal
+    of the multi-rank path) rows are staged through host memory -- a test vehicle, never the measured path."""
     import torch.distributed as dist
-    ops = []
-    for (peer, t, a, b) in plan.sends(rank):
-        ops.append(dist.P2POp(dist.isend, local_tiles[t][a:b], peer, group))
-    for (peer, t, a, b) in plan.recvs(rank):
-        ops.append(dist.P2POp(dist.irecv, recv_bufs[t], peer, group))
-    if not ops:
+    sends, recvs = plan.sends(rank), plan.recvs(rank)
+    if not sends and not recvs:
         return []
+    on_gpu = any(t.is_cuda for t in list(local_tiles.values()) + list(recv_bufs.values()))
+    if on_gpu and dist.get_backend(group) == "gloo":
+        works = []
+        for (peer, t, a, b) in sends:
+            works.append(_StagedWork(dist.isend(local_tiles[t][a:b].cpu(), peer, group=group, tag=t)))
+        for (peer, t, a, b) in recvs:
+            host = recv_bufs[t].new_empty(recv_bufs[t].shape, device="cpu")
+            works.append(_StagedWork(dist.irecv(host, peer, group=group, tag=t), host, recv_bufs[t]))
+        return works
+    ops = []
+    for (peer, t, a, b) in sends:
+        ops.append(dist.P2POp(dist.isend, local_tiles[t][a:b], peer, group))
+    for (peer, t, a, b) in recvs:
+        ops.append(dist.P2POp(dist.irecv, recv_bufs[t], peer, group))
     return dist.batch_isend_irecv(ops)
 
 
@@ -288,7 +313,12 @@ class DevicePipeline:
     def stage_reduce(self):
         if self.world > 1:
             import torch.distributed as dist
-            dist.all_reduce(self.results, op=dist.ReduceOp.SUM, group=self.group)
+            if dist.get_backend(self.group) == "gloo":          # rehearsal backend: reduce on the host
+                host = self.results.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                self.results.copy_(host)
+            else:
+                dist.all_reduce(self.results, op=dist.ReduceOp.SUM, group=self.group)
 
     def step(self, image, reference):
         self.stage_tile(image)
