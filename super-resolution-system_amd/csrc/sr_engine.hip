@@ -245,7 +245,7 @@ struct TileSrc {
     long long stride;
 };
 
-// What the final gather needs of one tile, 80 bytes = 5 x 16: staged into LDS for the candidates of a block.
+// What the final gather needs of one tile, 80 bytes (wave-uniform: read through the scalar cache).
 struct FinalDesc {
     int x, y, w, h;
     int fw, lut_off, nl, pad0;
@@ -254,7 +254,7 @@ struct FinalDesc {
     const void *src;       // level-0 tile data (row 0, possibly virtual) and its row stride in bytes
     long long stride;
 };
-static_assert(sizeof(FinalDesc) == 80, "FinalDesc is copied as five 16-byte words");
+static_assert(sizeof(FinalDesc) == 80, "FinalDesc layout");
 
 enum { SRC_U8 = 0, SRC_F32 = 1, SRC_PLANAR = 2, SRC_LUT = 3 };
 
@@ -722,26 +722,58 @@ __device__ __forceinline__ void up_regs(const f4_t (&q)[3], float (&u)[2][4])
     }
 }
 
-// interior visit: every global load of the visit is issued before the first use, then straight-line arithmetic
+// weights of an interior visit (all eight pixels inside the tile).  The LUT is monotone in the edge distance, so
+// lut[min(dy, dx)] == min(lut[dy], lut[dx]) exactly: 2 + 4 LUT reads and 8 v_min_f32 instead of 8 reads behind
+// 8 three-way integer minima.
+__device__ __forceinline__ void tile_weights_interior(const FinalDesc &D, const float *__restrict__ luts, int lx0, int ly0,
+                                                      float (&w0)[2][4])
+{
+    const int dmin = min(min(ly0, D.h - 2 - ly0), min(lx0, D.w - 4 - lx0));
+    const float *lut = luts + D.lut_off;
+    if (dmin >= D.fw) {
+        const float wf = lut[D.fw];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w0[j][k] = wf;
+        return;
+    }
+    float fy[2], fx[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fy[j] = lut[min(min(ly0 + j, D.h - 1 - ly0 - j), D.fw)];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) fx[k] = lut[min(min(lx0 + k, D.w - 1 - lx0 - k), D.fw)];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w0[j][k] = __builtin_fminf(fy[j], fx[k]);
+}
+
+// interior visit: every global load of the visit is issued before the first use, then straight-line arithmetic.
+// Plane bases are wave-uniform (SGPR pair); the per-lane part of an address is one 32-bit byte offset.
 template <int DT, bool LAP, int CN, bool XO, bool YO>
 __device__ __forceinline__ void gather_tile_fast(const FinalDesc &D, const float *__restrict__ arena,
                                                  const float *__restrict__ luts, int lx0, int ly0,
                                                  float (&acc)[2][4][CN], float (&wacc)[2][4])
 {
-    const int r0 = (ly0 - 1) >> 1, c0 = (lx0 - 1) >> 1;
     const bool pyr = LAP && D.nl > 1;
-    const size_t splane = (size_t)D.H1 * D.P1;
     // ---- loads -----------------------------------------------------------------------------------------
     f4_t qg[CN][3], qr[CN][3];
     if (pyr) {
-        const size_t o = (size_t)r0 * D.P1 + c0;
+        const int r0 = (ly0 - 1) >> 1, c0 = (lx0 - 1) >> 1;
+        const size_t splane = (size_t)D.H1 * D.P1;
+        const unsigned rowb = (unsigned)D.P1 * 4u;
+        const unsigned o = (unsigned)r0 * rowb + (unsigned)c0 * 4u;      // byte offset inside a plane (planes < 4 GB)
 #pragma unroll
-        for (int c = 0; c < CN; ++c)
+        for (int c = 0; c < CN; ++c) {
+            const char *gb = (const char *)(arena + D.g1 + c * splane);
+            const char *rb = (const char *)(arena + D.r1 + c * splane);
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                qg[c][r] = ld_f4_a4(arena + D.g1 + c * splane + o + (size_t)r * D.P1);
-                qr[c][r] = ld_f4_a4(arena + D.r1 + c * splane + o + (size_t)r * D.P1);
+                qg[c][r] = ld_f4_a4((const float *)(gb + (o + r * rowb)));
+                qr[c][r] = ld_f4_a4((const float *)(rb + (o + r * rowb)));
             }
+        }
     }
     float g0[2][4][CN];
     u3_t qs[2];
@@ -761,7 +793,7 @@ __device__ __forceinline__ void gather_tile_fast(const FinalDesc &D, const float
         }
     }
     float w0[2][4];
-    tile_weights(D, luts, lx0, ly0, w0);
+    tile_weights_interior(D, luts, lx0, ly0, w0);
     // ---- arithmetic ----------------------------------------------------------------------------------------
     if (DT == SRC_U8 && CN == 3) {
 #pragma unroll
@@ -771,27 +803,28 @@ __device__ __forceinline__ void gather_tile_fast(const FinalDesc &D, const float
             for (int b = 0; b < 12; ++b) g0[j][b / 3][b % 3] = (float)((wds[b >> 2] >> (8 * (b & 3))) & 0xFFu);
         }
     }
+    if (pyr) {                               // tile-uniform: a real branch, not a select per value
 #pragma unroll
-    for (int c = 0; c < CN; ++c) {
-        float ug[2][4], ur[2][4];
-        if (pyr) {
+        for (int c = 0; c < CN; ++c) {
+            float ug[2][4], ur[2][4];
             up_regs<XO, YO>(qg[c], ug);
             up_regs<XO, YO>(qr[c], ur);
-        }
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float r;
-                if (pyr) {
+                for (int k = 0; k < 4; ++k) {
                     const float lap = g0[j][k][c] - ug[j][k];
                     const float wl = lap * w0[j][k];
-                    r = ur[j][k] + wl;
-                } else {
-                    r = g0[j][k][c] * w0[j][k];
+                    acc[j][k][c] += ur[j][k] + wl;
                 }
-                acc[j][k][c] += r;
-            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < CN; ++c)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[j][k][c] += g0[j][k][c] * w0[j][k];
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -918,72 +951,54 @@ __global__ __launch_bounds__(256) void k_up_level_blk(const TileDev *__restrict_
     else up_level_thread<CN, false>(T, lvl, arena, x0, y0, ny);
 }
 
-#define FINAL_MAX_CAND 48
-
-// Candidate tiles of one 256 x 8 pixel block, in list order (wave 0, ballot-compacted), and their descriptors
-// copied into LDS.  Returns the count (> FINAL_MAX_CAND: list overflowed, walk every tile from global memory).
-__device__ __forceinline__ int block_candidates(const FinalDesc *__restrict__ descs, int n, int bx0, int by0, int bx1,
-                                                int by1, int *s_cnt, int *s_list, FinalDesc *s_desc)
+// a / w for the channels of one pixel, IEEE-correct: exactly the fma chain the compiler emits for an fp32 division
+// (rcp, one Newton step, quotient, two residual corrections) without the v_div_scale / v_div_fixup wrapping, which is
+// the identity for these operands (w in [1e-6, n_tiles], |a| a few thousand at most) -- and with the reciprocal
+// refined once per pixel instead of once per channel.
+template <int CN>
+__device__ __forceinline__ void div_shared(const float (&a)[CN], float w, float (&q)[CN])
 {
-    const int tid = threadIdx.y * 64 + threadIdx.x;
-    if (tid < 64) {
-        int cnt = 0;
-        for (int base = 0; base < n; base += 64) {
-            const int t = base + tid;
-            bool hit = false;
-            if (t < n) {
-                const int4 r = *(const int4 *)&descs[t];      // x, y, w, h
-                hit = r.x < bx1 && r.x + r.z > bx0 && r.y < by1 && r.y + r.w > by0;
-            }
-            const unsigned long long m = __ballot(hit);
-            if (hit) {
-                const int pos = cnt + __popcll(m & ((1ull << tid) - 1ull));
-                if (pos < FINAL_MAX_CAND) s_list[pos] = t;
-            }
-            cnt += __popcll(m);
-        }
-        if (tid == 0) *s_cnt = cnt;
+    float r = __builtin_amdgcn_rcpf(w);
+    r = fmaf(fmaf(-w, r, 1.0f), r, r);
+#pragma unroll
+    for (int c = 0; c < CN; ++c) {
+        float t = a[c] * r;
+        t = fmaf(fmaf(-w, t, a[c]), r, t);
+        q[c] = fmaf(fmaf(-w, t, a[c]), r, t);
     }
-    __syncthreads();
-    const int cnt = *s_cnt;
-    if (cnt <= FINAL_MAX_CAND) {
-        for (int i = tid; i < cnt * 5; i += 256) {
-            const int e = i / 5, q = i - e * 5;
-            ((int4 *)s_desc)[i] = ((const int4 *)&descs[s_list[e]])[q];
-        }
-        __syncthreads();
-    }
-    return cnt;
 }
 
 // normalise, clip, truncate and store the thread's pixels
 template <int CN>
-__device__ __forceinline__ void store_pixels(const float (&acc)[2][4][CN], const float (&wacc)[2][4],
+__device__ __forceinline__ void store_pixels(float (&acc)[2][4][CN], const float (&wacc)[2][4],
                                              unsigned char *__restrict__ canvas, long long cstride,
                                              float *__restrict__ canvas_f32, int cw, int x0, int y0, int nx, int ny)
 {
     const bool vec_ok = (CN == 3) && nx == 4 && ((cstride & 3) == 0) && ((((size_t)canvas) & 3) == 0);
     // x / 1.0f == x: where every pixel of the wave has sum-of-weights exactly 1 (single coverage beyond the
-    // feather zone, about half of a grid canvas) the IEEE division sequences are skipped -- wave-uniform branch
+    // feather zone, about half of a grid canvas) the divisions are skipped -- wave-uniform branch
     bool ones = true;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int k = 0; k < 4; ++k) ones = ones && (wacc[j][k] == 1.0f);
-    const bool no_div = __all(ones) != 0;
+    if (__all(ones) == 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) div_shared<CN>(acc[j][k], __builtin_fmaxf(wacc[j][k], 1e-6f), acc[j][k]);
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         if (j >= ny) break;
-        unsigned char ob[4 * CN];
+        unsigned ob[4 * CN];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float wv = wacc[j][k] > 1e-6f ? wacc[j][k] : 1e-6f;
 #pragma unroll
             for (int c = 0; c < CN; ++c) {
-                const float v = no_div ? acc[j][k][c] : acc[j][k][c] / wv;
+                const float v = acc[j][k][c];
                 if (canvas_f32 && k < nx) canvas_f32[((size_t)(y0 + j) * cw + x0 + k) * CN + c] = v;
-                const float cl = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
-                ob[k * CN + c] = (unsigned char)cl;
+                ob[k * CN + c] = (unsigned)__builtin_amdgcn_fmed3f(v, 0.0f, 255.0f);     // clip, then truncate
             }
         }
         unsigned char *o = canvas + (size_t)(y0 + j) * cstride + (size_t)x0 * CN;
@@ -991,36 +1006,35 @@ __device__ __forceinline__ void store_pixels(const float (&acc)[2][4][CN], const
             unsigned int *o32 = (unsigned int *)o;
 #pragma unroll
             for (int q = 0; q < 3; ++q)
-                o32[q] = (unsigned)ob[4 * q] | ((unsigned)ob[4 * q + 1] << 8) | ((unsigned)ob[4 * q + 2] << 16) |
-                         ((unsigned)ob[4 * q + 3] << 24);
+                o32[q] = ob[4 * q] | (ob[4 * q + 1] << 8) | (ob[4 * q + 2] << 16) | (ob[4 * q + 3] << 24);
         } else {
             for (int k = 0; k < nx; ++k)
 #pragma unroll
-                for (int c = 0; c < CN; ++c) o[k * CN + c] = ob[k * CN + c];
+                for (int c = 0; c < CN; ++c) o[k * CN + c] = (unsigned char)ob[k * CN + c];
         }
     }
 }
 
+// Candidate tiles of a 256 x 8 pixel block come from a table built on the host when the plan is made (the tile
+// arrangement is fixed per plan): cand_off[blk] .. cand_off[blk + 1] index cand_idx, tiles in list order.  Block
+// id, list entries and the 80-byte descriptors are wave-uniform, so they travel through the scalar cache into
+// SGPRs: no LDS staging and no barrier before the first vector load.
+
 // Final gather, pass 1: threads all of whose tile visits are interior.  Threads with any border visit leave
 // their pixels to k_final_edge.
 template <int DT, bool LAP, int CN>
-__global__ __launch_bounds__(256, 3) void k_final_fast(const FinalDesc *__restrict__ descs, int n,
+__global__ __launch_bounds__(256, 3) void k_final_fast(const FinalDesc *__restrict__ descs,
+                                                       const int *__restrict__ cand_off, const int *__restrict__ cand_idx,
                                                        const float *__restrict__ arena, const float *__restrict__ luts,
                                                        unsigned char *__restrict__ canvas, long long cstride,
                                                        float *__restrict__ canvas_f32, int cw, int row_begin, int row_end)
 {
-    __shared__ int s_cnt;
-    __shared__ int s_list[FINAL_MAX_CAND];
-    __shared__ FinalDesc s_desc[FINAL_MAX_CAND];
-    const int bx0 = blockIdx.x * 256, by0 = row_begin + blockIdx.y * 8;
-    const int ncand = block_candidates(descs, n, bx0, by0, min(bx0 + 256, cw), min(by0 + 8, row_end), &s_cnt, s_list, s_desc);
+    const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+    const int c_begin = cand_off[blk], c_end = cand_off[blk + 1];
     const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int y0 = row_begin + (blockIdx.y * 4 + threadIdx.y) * 2;
     if (x0 >= cw || y0 >= row_end) return;
     const int nx = min(4, cw - x0), ny = min(2, row_end - y0);
-    const bool overflow = ncand > FINAL_MAX_CAND;
-    const FinalDesc *dl = overflow ? descs : s_desc;
-    const int nloop = overflow ? n : ncand;
     float acc[2][4][CN], wacc[2][4];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -1030,8 +1044,8 @@ __global__ __launch_bounds__(256, 3) void k_final_fast(const FinalDesc *__restri
 #pragma unroll
             for (int c = 0; c < CN; ++c) acc[j][k][c] = 0.f;
         }
-    for (int i = 0; i < nloop; ++i) {
-        const FinalDesc D = dl[i];
+    for (int i = c_begin; i < c_end; ++i) {
+        const FinalDesc &D = descs[cand_idx[i]];
         const int lx0 = x0 - D.x, ly0 = y0 - D.y;
         if (lx0 + nx <= 0 || ly0 + ny <= 0 || lx0 >= D.w || ly0 >= D.h) continue;
         // one border visit sends the whole thread to the edge pass (which recomputes every visit)
@@ -1046,34 +1060,29 @@ __global__ __launch_bounds__(256, 3) void k_final_fast(const FinalDesc *__restri
     store_pixels<CN>(acc, wacc, canvas, cstride, canvas_f32, cw, x0, y0, nx, ny);
 }
 
-// Final gather, pass 2: the threads pass 1 left out (a border visit).  Launched only over the blocks a tile
-// border (or the ragged canvas edge) comes near -- the list is built on the host when the plan is made.
+// Final gather, pass 2: the threads pass 1 left out (a border visit).  Launched only over the blocks of the edge
+// work list built on the host when the plan is made: 256 x 8 pixel blocks along horizontal tile edges (shape 0),
+// 16 x 128 pixel blocks along vertical ones (shape 1).
 template <int DT, bool LAP, int CN>
-__global__ __launch_bounds__(256) void k_final_edge(const FinalDesc *__restrict__ descs, int n,
-                                                    const int2 *__restrict__ edge_blocks,
+__global__ __launch_bounds__(256) void k_final_edge(const FinalDesc *__restrict__ descs,
+                                                    const int4 *__restrict__ edge_blocks, const int *__restrict__ cand_idx,
                                                     const float *__restrict__ arena, const float *__restrict__ luts,
                                                     unsigned char *__restrict__ canvas, long long cstride,
                                                     float *__restrict__ canvas_f32, int cw, int row_begin, int row_end)
 {
-    __shared__ int s_cnt;
-    __shared__ int s_list[FINAL_MAX_CAND];
-    __shared__ FinalDesc s_desc[FINAL_MAX_CAND];
-    const int2 bxy = edge_blocks[blockIdx.x];
-    const int bx0 = bxy.x * 256, by0 = row_begin + bxy.y * 8;
-    const int ncand = block_candidates(descs, n, bx0, by0, min(bx0 + 256, cw), min(by0 + 8, row_end), &s_cnt, s_list, s_desc);
-    const int x0 = (bxy.x * 64 + threadIdx.x) * 4;
-    const int y0 = row_begin + (bxy.y * 4 + threadIdx.y) * 2;
+    const int4 eb = edge_blocks[blockIdx.x];
+    const int c_begin = eb.w, c_end = edge_blocks[blockIdx.x + 1].w;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const int x0 = eb.x + (eb.z ? (tid & 3) : (tid & 63)) * 4;
+    const int y0 = eb.y + (eb.z ? (tid >> 2) : (tid >> 6)) * 2;
     if (x0 >= cw || y0 >= row_end) return;
     const int nx = min(4, cw - x0), ny = min(2, row_end - y0);
-    const bool overflow = ncand > FINAL_MAX_CAND;
-    const FinalDesc *dl = overflow ? descs : s_desc;
-    const int nloop = overflow ? n : ncand;
     bool edge = false;
-    for (int i = 0; i < nloop; ++i) {
-        const int4 r = *(const int4 *)&dl[i];
-        const int lx0 = x0 - r.x, ly0 = y0 - r.y;
-        if (lx0 + nx <= 0 || ly0 + ny <= 0 || lx0 >= r.z || ly0 >= r.w) continue;
-        if (!visit_is_interior<LAP>(dl[i], lx0, ly0, nx, ny)) edge = true;
+    for (int i = c_begin; i < c_end; ++i) {
+        const FinalDesc &D = descs[cand_idx[i]];
+        const int lx0 = x0 - D.x, ly0 = y0 - D.y;
+        if (lx0 + nx <= 0 || ly0 + ny <= 0 || lx0 >= D.w || ly0 >= D.h) continue;
+        if (!visit_is_interior<LAP>(D, lx0, ly0, nx, ny)) edge = true;
     }
     if (!edge) return;
     float acc[2][4][CN], wacc[2][4];
@@ -1085,8 +1094,8 @@ __global__ __launch_bounds__(256) void k_final_edge(const FinalDesc *__restrict_
 #pragma unroll
             for (int c = 0; c < CN; ++c) acc[j][k][c] = 0.f;
         }
-    for (int i = 0; i < nloop; ++i) {
-        const FinalDesc D = dl[i];
+    for (int i = c_begin; i < c_end; ++i) {
+        const FinalDesc &D = descs[cand_idx[i]];
         const int lx0 = x0 - D.x, ly0 = y0 - D.y;
         if (lx0 + nx <= 0 || ly0 + ny <= 0 || lx0 >= D.w || ly0 >= D.h) continue;
         unsigned valid = 0;
@@ -1608,8 +1617,8 @@ __global__ __launch_bounds__(256) void k_assess_march(const unsigned char *__res
                 // byte products into v_perm_b32 + v_dot4_u32_u8 sequences that gave wrong sums (seen in an earlier kernel)
                 asm volatile("" : "+v"(xv[j]), "+v"(yv[j]));
                 const int sm = xv[j] + yv[j], df = xv[j] - yv[j];
-                pv[j] = sm * sm;
-                qv[j] = df * df;
+                pv[j] = __mul24(sm, sm);                         // |sm| <= 510: full-rate 24-bit multiply
+                qv[j] = __mul24(df, df);
             }
             if (do_g) {
                 double hx = (double)xv[5] * P.k[0], hy = (double)yv[5] * P.k[0];
@@ -1890,8 +1899,10 @@ struct sr_blend_plan {
     TileSrc *d_srcs = nullptr;
     FinalDesc *d_fdesc = nullptr;
     std::vector<FinalDesc> fdesc;
-    int2 *d_edge_blocks = nullptr;
+    int4 *d_edge_blocks = nullptr;                      // edge pass work list: x0, y0, shape, first candidate
+    int *d_edge_cand = nullptr;
     int n_edge_blocks = 0;
+    int *d_cand_off = nullptr, *d_cand_idx = nullptr;   // per 256 x 8 block: candidate tiles (CSR, list order)
     float *d_luts = nullptr;
     // launch extents per level
     int max_w[SR_MAX_LEVELS] = {0}, max_grows[SR_MAX_LEVELS] = {0}, max_rrows[SR_MAX_LEVELS] = {0};
@@ -2240,6 +2251,9 @@ int sr_blend_plan_destroy(sr_blend_plan *plan)
         if (plan->d_srcs) (void)hipFree(plan->d_srcs);
         if (plan->d_fdesc) (void)hipFree(plan->d_fdesc);
         if (plan->d_edge_blocks) (void)hipFree(plan->d_edge_blocks);
+        if (plan->d_edge_cand) (void)hipFree(plan->d_edge_cand);
+        if (plan->d_cand_off) (void)hipFree(plan->d_cand_off);
+        if (plan->d_cand_idx) (void)hipFree(plan->d_cand_idx);
         if (plan->d_luts) (void)hipFree(plan->d_luts);
     }
     delete plan;
@@ -2407,40 +2421,92 @@ int sr_blend_plan_create(sr_ctx *ctx, const sr_tile_rect *h_tiles, int n, int cn
     }
     if ((e = hipMalloc((void **)&P->d_luts, sizeof(float) * P->luts.size())) != hipSuccess) return fail(e, "luts");
     {
-        // blocks (256 x 8 canvas pixels, origin (0, row_begin)) within 16 px of a tile edge line or on the ragged
-        // right / bottom canvas edge: the only blocks in which a visit can be a border visit
+        // Edge work list: the cells (4 x 2 pixel rectangles of one thread) in which a visit can be a border visit lie
+        // within 8 px of a tile edge line (or on the ragged right / bottom canvas edge).  Horizontal lines are
+        // covered by 256 x 8 blocks of the fast pass's grid (shape 0), vertical lines by 16 x 128 blocks (shape 1:
+        // 4 x 64 cells), so a wave of the edge pass is mostly border cells either way.  A cell reached through both
+        // shapes is computed twice with identical results.
         const int rows = row_end - row_begin;
         const int nbx = (canvas_w + 255) / 256, nby = (rows + 7) / 8;
+        const int nbx2 = (canvas_w + 15) / 16, nby2 = (rows + 127) / 128;
         std::vector<unsigned char> mark((size_t)std::max(nbx, 1) * std::max(nby, 1), 0);
-        auto mark_rect = [&](long long x0, long long y0, long long x1, long long y1) {   // canvas px, half-open
+        std::vector<unsigned char> mark2((size_t)std::max(nbx2, 1) * std::max(nby2, 1), 0);
+        auto mark_rect = [&](std::vector<unsigned char> &m, int gx, int gy, int pitch, long long x0, long long y0,
+                             long long x1, long long y1) {   // canvas px, half-open
             x0 = std::max<long long>(x0, 0); x1 = std::min<long long>(x1, canvas_w);
             y0 = std::max<long long>(y0, row_begin); y1 = std::min<long long>(y1, row_end);
             if (x0 >= x1 || y0 >= y1) return;
-            for (long long by = (y0 - row_begin) / 8; by <= (y1 - 1 - row_begin) / 8; ++by)
-                for (long long bx = x0 / 256; bx <= (x1 - 1) / 256; ++bx) mark[(size_t)by * nbx + bx] = 1;
+            for (long long by = (y0 - row_begin) / gy; by <= (y1 - 1 - row_begin) / gy; ++by)
+                for (long long bx = x0 / gx; bx <= (x1 - 1) / gx; ++bx) m[(size_t)by * pitch + bx] = 1;
         };
-        const int M = 16;
+        const int M = 8;
         for (int t = 0; t < n && rows > 0; ++t) {
             const TileDev &T = P->tiles[t];
             const long long xa = T.x, xb = (long long)T.x + T.w, ya = T.y, yb = (long long)T.y + T.h;
-            mark_rect(xa - M, ya - M, xa + M, yb + M);
-            mark_rect(xb - M, ya - M, xb + M, yb + M);
-            mark_rect(xa - M, ya - M, xb + M, ya + M);
-            mark_rect(xa - M, yb - M, xb + M, yb + M);
+            mark_rect(mark2, 16, 128, nbx2, xa - M, ya - M, xa + M, yb + M);
+            mark_rect(mark2, 16, 128, nbx2, xb - M, ya - M, xb + M, yb + M);
+            mark_rect(mark, 256, 8, nbx, xa - M, ya - M, xb + M, ya + M);
+            mark_rect(mark, 256, 8, nbx, xa - M, yb - M, xb + M, yb + M);
         }
         if (rows > 0) {
-            if (canvas_w % 4) mark_rect(canvas_w - 4, row_begin, canvas_w, row_end);
-            if (rows % 2) mark_rect(0, row_end - 2, canvas_w, row_end);
+            if (canvas_w % 4) mark_rect(mark2, 16, 128, nbx2, canvas_w - 4, row_begin, canvas_w, row_end);
+            if (rows % 2) mark_rect(mark, 256, 8, nbx, 0, row_end - 2, canvas_w, row_end);
         }
-        std::vector<int2> eb;
+        std::vector<int4> eb;                       // x0, y0 (canvas), shape, first candidate
         for (int by = 0; by < nby; ++by)
             for (int bx = 0; bx < nbx; ++bx)
-                if (mark[(size_t)by * nbx + bx]) eb.push_back(make_int2(bx, by));
-        P->n_edge_blocks = (int)eb.size();
-        if (!eb.empty()) {
-            if ((e = hipMalloc((void **)&P->d_edge_blocks, sizeof(int2) * eb.size())) != hipSuccess) return fail(e, "edge blocks");
-            if ((e = hipMemcpy(P->d_edge_blocks, eb.data(), sizeof(int2) * eb.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload");
+                if (mark[(size_t)by * nbx + bx]) eb.push_back(make_int4(bx * 256, row_begin + by * 8, 0, 0));
+        for (int by = 0; by < nby2; ++by)
+            for (int bx = 0; bx < nbx2; ++bx)
+                if (mark2[(size_t)by * nbx2 + bx]) eb.push_back(make_int4(bx * 16, row_begin + by * 128, 1, 0));
+        std::vector<int> ecand;
+        for (auto &e4 : eb) {
+            const long long bx0 = e4.x, by0 = e4.y;
+            const long long bx1 = std::min<long long>(bx0 + (e4.z ? 16 : 256), canvas_w);
+            const long long by1 = std::min<long long>(by0 + (e4.z ? 128 : 8), row_end);
+            e4.w = (int)ecand.size();
+            for (int t = 0; t < n; ++t) {
+                const TileDev &T = P->tiles[t];
+                if (T.x < bx1 && (long long)T.x + T.w > bx0 && T.y < by1 && (long long)T.y + T.h > by0) ecand.push_back(t);
+            }
         }
+        eb.push_back(make_int4(0, 0, 0, (int)ecand.size()));       // sentinel: end of the last list
+        P->n_edge_blocks = (int)eb.size() - 1;
+        if (P->n_edge_blocks > 0) {
+            if ((e = hipMalloc((void **)&P->d_edge_blocks, sizeof(int4) * eb.size())) != hipSuccess) return fail(e, "edge blocks");
+            if ((e = hipMemcpy(P->d_edge_blocks, eb.data(), sizeof(int4) * eb.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload");
+            if ((e = hipMalloc((void **)&P->d_edge_cand, sizeof(int) * std::max<size_t>(ecand.size(), 1))) != hipSuccess) return fail(e, "edge candidates");
+            if (!ecand.empty() && (e = hipMemcpy(P->d_edge_cand, ecand.data(), sizeof(int) * ecand.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload");
+        }
+        // candidate tiles per block, CSR, tiles in list order (the accumulation order of the reference)
+        const size_t nblk = (size_t)std::max(nbx, 1) * std::max(nby, 1);
+        std::vector<int> coff(nblk + 1, 0);
+        auto block_span = [&](const TileDev &T, int &bx_a, int &bx_b, int &by_a, int &by_b) {
+            const long long x0 = std::max<long long>(T.x, 0), x1 = std::min<long long>((long long)T.x + T.w, canvas_w);
+            const long long y0 = std::max<long long>(T.y, row_begin), y1 = std::min<long long>((long long)T.y + T.h, row_end);
+            if (x0 >= x1 || y0 >= y1) return false;
+            bx_a = (int)(x0 / 256); bx_b = (int)((x1 - 1) / 256);
+            by_a = (int)((y0 - row_begin) / 8); by_b = (int)((y1 - 1 - row_begin) / 8);
+            return true;
+        };
+        for (int t = 0; t < n && rows > 0; ++t) {
+            int bxa, bxb, bya, byb;
+            if (!block_span(P->tiles[t], bxa, bxb, bya, byb)) continue;
+            for (int by = bya; by <= byb; ++by)
+                for (int bx = bxa; bx <= bxb; ++bx) ++coff[(size_t)by * nbx + bx + 1];
+        }
+        for (size_t i = 0; i < nblk; ++i) coff[i + 1] += coff[i];
+        std::vector<int> cidx((size_t)std::max(coff[nblk], 1), 0), fill(coff.begin(), coff.end() - 1);
+        for (int t = 0; t < n && rows > 0; ++t) {
+            int bxa, bxb, bya, byb;
+            if (!block_span(P->tiles[t], bxa, bxb, bya, byb)) continue;
+            for (int by = bya; by <= byb; ++by)
+                for (int bx = bxa; bx <= bxb; ++bx) cidx[(size_t)fill[(size_t)by * nbx + bx]++] = t;
+        }
+        if ((e = hipMalloc((void **)&P->d_cand_off, sizeof(int) * coff.size())) != hipSuccess) return fail(e, "candidate table");
+        if ((e = hipMalloc((void **)&P->d_cand_idx, sizeof(int) * cidx.size())) != hipSuccess) return fail(e, "candidate table");
+        if ((e = hipMemcpy(P->d_cand_off, coff.data(), sizeof(int) * coff.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload");
+        if ((e = hipMemcpy(P->d_cand_idx, cidx.data(), sizeof(int) * cidx.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload");
     }
     if ((e = hipMemcpyAsync(P->d_tiles, P->tiles.data(), sizeof(TileDev) * n, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e, "upload");
     if ((e = hipMemcpyAsync(P->d_classes, P->classes.data(), sizeof(TileDev) * P->classes.size(), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e, "upload");
@@ -2605,12 +2671,12 @@ static int blend_gather(sr_blend_plan *P, bool lap, int dtype, void *const *h_d_
             dim3 grid((P->canvas_w + 255) / 256, (rows + 7) / 8);
 #define LAUNCH_BLK(DT, LAPV, CNV)                                                                               \
     do {                                                                                                        \
-        hipLaunchKernelGGL((k_final_fast<DT, LAPV, CNV>), grid, block, 0, ctx->stream, P->d_fdesc, P->n,          \
-                           P->d_arena, P->d_luts, d_canvas, (long long)canvas_stride, d_canvas_f32, P->canvas_w,  \
-                           P->row_begin, P->row_end);                                                            \
+        hipLaunchKernelGGL((k_final_fast<DT, LAPV, CNV>), grid, block, 0, ctx->stream, P->d_fdesc,                \
+                           P->d_cand_off, P->d_cand_idx, P->d_arena, P->d_luts, d_canvas,                        \
+                           (long long)canvas_stride, d_canvas_f32, P->canvas_w, P->row_begin, P->row_end);       \
         if (P->n_edge_blocks > 0)                                                                               \
             hipLaunchKernelGGL((k_final_edge<DT, LAPV, CNV>), dim3(P->n_edge_blocks), block, 0, ctx->stream,       \
-                               P->d_fdesc, P->n, P->d_edge_blocks, P->d_arena, P->d_luts, d_canvas,               \
+                               P->d_fdesc, P->d_edge_blocks, P->d_edge_cand, P->d_arena, P->d_luts, d_canvas,      \
                                (long long)canvas_stride, d_canvas_f32, P->canvas_w, P->row_begin, P->row_end);   \
     } while (0)
             if (P->cn == 3) {
