@@ -345,106 +345,181 @@ __global__ __launch_bounds__(256) void k_down(const TileDev *__restrict__ tiles,
     down_pixel<SRC>(T, S, lvl, cn, x, y, arena, luts);
 }
 
-// Register-blocked pyrDown: one thread = 4 x 2 outputs of every plane.  The 7 x 11 input window is read
-// once per plane with vector loads (u8: three byte-aligned 12-byte loads per row for all channels;
-// planar fp32: float2 + float4 + float4 + float), the row pass is evaluated once per input row and
-// shared by the two output rows.  Threads whose window touches a border use down_pixel per output.
+// ---------------------------------------------------------------------------------------------
+// Column-marching pyrDown.  One thread owns 4 output columns (a "column group": output x0 = 4 * cg, input columns
+// 2 x0 - 2 .. 2 x0 + 8) and walks down DM_ROWS output rows: every input row is loaded once and its horizontal pass
+// evaluated once; the five row-pass results an output row needs (rows 2y-2 .. 2y+2) live in registers.  Row indices
+// go through REFLECT_101, so the top / bottom tile borders need no separate path.  Only "interior" column groups
+// (whole window inside the row: cg = 1 .. ncg) run here; the few border columns of a level go to k_down_cols.
+// Lanes are laid over (segment, column group) cells flattened per tile, so waves are full except the last one.
+// ---------------------------------------------------------------------------------------------
+#define DM_ROWS 16
+
+// number of interior column groups of a level: cg = 1 .. ncg
+__host__ __device__ __forceinline__ int down_ncg(int ws, int wo)
+{
+    const int a = ws >= 10 ? (ws - 10) / 8 : 0;     // 2 x0 + 9 <= ws - 1
+    const int b = wo >= 4 ? (wo - 4) / 4 : 0;       // x0 + 3 <= wo - 1
+    return a < b ? a : b;
+}
+
+// horizontal pass of one u8 row for the thread's 4 outputs x CN channels.  All values are integers below 2^24, so
+// fp32 evaluates them exactly in any order: bit-identical to ((s2*6 + (s1+s3)*4) + s0) + s4 with two fmas.
+template <int CN>
+__device__ __forceinline__ void down_row_u8(const unsigned (&wds)[(CN == 3) ? 9 : 3], float (&h)[4 * CN])
+{
+    float s[11][CN];
+#pragma unroll
+    for (int b = 0; b < 11 * CN; ++b) s[b / CN][b % CN] = (float)((wds[b >> 2] >> (8 * (b & 3))) & 0xFFu);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int c = 0; c < CN; ++c)
+            h[k * CN + c] = fmaf(s[2 * k + 2][c], 6.0f, fmaf(s[2 * k + 1][c] + s[2 * k + 3][c], 4.0f, s[2 * k][c] + s[2 * k + 4][c]));
+}
+
+template <int CN>
+__device__ __forceinline__ void down_load_u8(const unsigned char *__restrict__ base, long long stride, int row, int xb,
+                                             unsigned (&wds)[(CN == 3) ? 9 : 3])
+{
+    const unsigned char *p = base + (size_t)row * stride + (size_t)xb * CN;
+    if (CN == 3) {
+        const u3_t q0 = ld_u3_a1(p), q1 = ld_u3_a1(p + 12), q2 = ld_u3_a1(p + 24);
+        wds[0] = q0.x; wds[1] = q0.y; wds[2] = q0.z; wds[3] = q1.x; wds[4] = q1.y; wds[5] = q1.z;
+        wds[6] = q2.x; wds[7] = q2.y; wds[8] = q2.z;
+    } else {
+        const u3_t q0 = ld_u3_a1(p);
+        wds[0] = q0.x; wds[1] = q0.y; wds[2] = q0.z;
+    }
+}
+
+__device__ __forceinline__ void down_load_f32(const float *__restrict__ plane, int ps, int row, int xb, float (&s)[11])
+{
+    const float *p = plane + (size_t)row * ps + xb;          // xb = 8 cg - 2: 8-byte aligned, xb + 2 16-byte aligned
+    const f2_t a = *(const f2_a8_t *)p;
+    const f4_t b = ld_f4(p + 2), d = ld_f4(p + 6);
+    s[0] = a.x; s[1] = a.y; s[2] = b.x; s[3] = b.y; s[4] = b.z; s[5] = b.w; s[6] = d.x; s[7] = d.y; s[8] = d.z; s[9] = d.w;
+    s[10] = p[10];
+}
+
+__device__ __forceinline__ void down_row_f32(const float (&s)[11], float (&h)[4])
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) h[k] = ((s[2 * k + 2] * 6.0f + (s[2 * k + 1] + s[2 * k + 3]) * 4.0f) + s[2 * k]) + s[2 * k + 4];
+}
 
 template <int SRC, int CN>
-__global__ __launch_bounds__(256) void k_down_blk(const TileDev *__restrict__ tiles, const TileSrc *__restrict__ srcs,
-                                                  int lvl, float *__restrict__ arena, const float *__restrict__ luts)
+__global__ __launch_bounds__(256) void k_down_march(const TileDev *__restrict__ tiles, const TileSrc *__restrict__ srcs,
+                                                    int lvl, float *__restrict__ arena)
 {
     const TileDev &T = tiles[blockIdx.z];
     if (lvl + 1 >= T.nl) return;
-    const int wo = T.W[lvl + 1];
-    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int y0 = T.g0[lvl + 1] + (blockIdx.y * 4 + threadIdx.y) * 2;
-    if (x0 >= wo || y0 >= T.g1[lvl + 1]) return;
-    const int nx = min(4, wo - x0), ny = min(2, T.g1[lvl + 1] - y0);
-    const int hs = T.H[lvl], ws = T.W[lvl];
-    TileSrc S;
-    S.p = nullptr;
-    S.stride = 0;
-    if (SRC == SRC_U8) S = srcs[blockIdx.z];
-    const bool interior = nx == 4 && 2 * x0 - 2 >= 0 && 2 * x0 + 9 <= ws - 1 && 2 * y0 - 2 >= 0 && 2 * y0 + 4 <= hs - 1;
-    if (!interior) {
-        for (int j = 0; j < ny; ++j)
-            for (int k = 0; k < nx; ++k) down_pixel<SRC>(T, S, lvl, CN, x0 + k, y0 + j, arena, luts);
-        return;
-    }
+    const int ws = T.W[lvl], hs = T.H[lvl], wo = T.W[lvl + 1];
+    const int ya = T.g0[lvl + 1], yb = T.g1[lvl + 1];
+    const int ncg = down_ncg(ws, wo);
+    if (ncg <= 0 || yb <= ya) return;
+    const int nseg = (yb - ya + DM_ROWS - 1) / DM_ROWS;
+    const int cell = blockIdx.x * 256 + threadIdx.y * 64 + threadIdx.x;
+    if (cell >= ncg * nseg) return;
+    const int seg = cell / ncg, x0 = (1 + cell - seg * ncg) * 4;
+    const int y_begin = ya + seg * DM_ROWS, y_end = min(y_begin + DM_ROWS, yb);
     const int po = T.P[lvl + 1];
     const size_t dplane = (size_t)T.H[lvl + 1] * po;
-    float *dst = arena + T.g_off[lvl + 1] + (size_t)y0 * po + x0;
+    float *dst = arena + T.g_off[lvl + 1] + x0;
+    const int xb = 2 * x0 - 2;
     if (SRC == SRC_U8) {
-        float hrow[7][CN][4];
-#pragma unroll
-        for (int r = 0; r < 7; ++r) {
-            // rows 5, 6 feed only the second output row; with ny == 1 they may lie outside the rows a strip owner
-            // holds of this tile (virtual base pointer), so they must not be touched
-            const int rr = (r >= 5 && ny < 2) ? 4 : r;
-            const unsigned char *row = (const unsigned char *)S.p + (size_t)(2 * y0 - 2 + rr) * S.stride + (size_t)(2 * x0 - 2) * CN;
-            float s[11][CN];
-            if (CN == 3) {
-                const u3_t q0 = ld_u3_a1(row), q1 = ld_u3_a1(row + 12), q2 = ld_u3_a1(row + 24);
-                const unsigned wds[9] = {q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, q2.x, q2.y, q2.z};
-#pragma unroll
-                for (int b = 0; b < 33; ++b) s[b / 3][b % 3] = (float)((wds[b >> 2] >> (8 * (b & 3))) & 0xFFu);
-            } else {
-                const u3_t q0 = ld_u3_a1(row);
-                const unsigned wds[3] = {q0.x, q0.y, q0.z};
-#pragma unroll
-                for (int b = 0; b < 11; ++b) s[b][0] = (float)((wds[b >> 2] >> (8 * (b & 3))) & 0xFFu);
+        constexpr int NW = (CN == 3) ? 9 : 3, NV = 4 * CN;
+        const TileSrc S = srcs[blockIdx.z];
+        const unsigned char *base = (const unsigned char *)S.p;
+        unsigned w0[NW], w1[NW];
+        float e0[NV], o0[NV], e1[NV], o1[NV], e2[NV];
+        down_load_u8<CN>(base, S.stride, reflect101(2 * y_begin - 2, hs), xb, w0);
+        down_row_u8<CN>(w0, e0);
+        down_load_u8<CN>(base, S.stride, reflect101(2 * y_begin - 1, hs), xb, w0);
+        down_row_u8<CN>(w0, o0);
+        down_load_u8<CN>(base, S.stride, 2 * y_begin, xb, w0);
+        down_row_u8<CN>(w0, e1);
+        down_load_u8<CN>(base, S.stride, reflect101(2 * y_begin + 1, hs), xb, w0);
+        down_load_u8<CN>(base, S.stride, reflect101(2 * y_begin + 2, hs), xb, w1);
+        for (int y = y_begin; y < y_end; ++y) {
+            down_row_u8<CN>(w0, o1);
+            down_row_u8<CN>(w1, e2);
+            if (y + 1 < y_end) {        // rows of the next output row: in flight during the arithmetic below
+                down_load_u8<CN>(base, S.stride, reflect101(2 * y + 3, hs), xb, w0);
+                down_load_u8<CN>(base, S.stride, reflect101(2 * y + 4, hs), xb, w1);
             }
 #pragma unroll
-            for (int c = 0; c < CN; ++c)
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    hrow[r][c][k] = ((s[2 * k + 2][c] * 6.0f + (s[2 * k + 1][c] + s[2 * k + 3][c]) * 4.0f) + s[2 * k][c]) + s[2 * k + 4][c];
-        }
-#pragma unroll
-        for (int c = 0; c < CN; ++c)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int c = 0; c < CN; ++c) {
+                f4_t ov;
                 float o[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float v = ((hrow[2 * j + 2][c][k] * 6.0f + (hrow[2 * j + 1][c][k] + hrow[2 * j + 3][c][k]) * 4.0f) + hrow[2 * j][c][k]) + hrow[2 * j + 4][c][k];
-                    o[k] = v * (1.0f / 256.0f);
+                    const int i = k * CN + c;    // integers below 2^24 again: exact in any order
+                    o[k] = fmaf(e1[i], 6.0f, fmaf(o0[i] + o1[i], 4.0f, e0[i] + e2[i])) * (1.0f / 256.0f);
                 }
-                f4_t ov;
                 ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
-                if (j < ny) st_f4(dst + c * dplane + (size_t)j * po, ov);
+                st_f4(dst + c * dplane + (size_t)y * po, ov);
             }
-    } else {  // SRC_PLANAR
+#pragma unroll
+            for (int i = 0; i < NV; ++i) { e0[i] = e1[i]; o0[i] = o1[i]; e1[i] = e2[i]; }
+        }
+    } else {  // SRC_PLANAR: fp32 rounds, the reference's evaluation order is kept
         const int ps = T.P[lvl];
         const size_t splane = (size_t)hs * ps;
 #pragma unroll 1
         for (int c = 0; c < CN; ++c) {
-            float hrow[7][4];
-#pragma unroll
-            for (int r = 0; r < 7; ++r) {
-                const float *row = arena + T.g_off[lvl] + c * splane + (size_t)(2 * y0 - 2 + r) * ps + (2 * x0 - 2);
-                const f2_t a = *(const f2_a8_t *)row;
-                const f4_t b = ld_f4(row + 2), d = ld_f4(row + 6);
-                const float s[11] = {a.x, a.y, b.x, b.y, b.z, b.w, d.x, d.y, d.z, d.w, row[10]};
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    hrow[r][k] = ((s[2 * k + 2] * 6.0f + (s[2 * k + 1] + s[2 * k + 3]) * 4.0f) + s[2 * k]) + s[2 * k + 4];
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float o[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float v = ((hrow[2 * j + 2][k] * 6.0f + (hrow[2 * j + 1][k] + hrow[2 * j + 3][k]) * 4.0f) + hrow[2 * j][k]) + hrow[2 * j + 4][k];
-                    o[k] = v * (1.0f / 256.0f);
+            const float *plane = arena + T.g_off[lvl] + c * splane;
+            float s0[11], s1[11];
+            float e0[4], o0[4], e1[4], o1[4], e2[4];
+            down_load_f32(plane, ps, reflect101(2 * y_begin - 2, hs), xb, s0);
+            down_row_f32(s0, e0);
+            down_load_f32(plane, ps, reflect101(2 * y_begin - 1, hs), xb, s0);
+            down_row_f32(s0, o0);
+            down_load_f32(plane, ps, 2 * y_begin, xb, s0);
+            down_row_f32(s0, e1);
+            down_load_f32(plane, ps, reflect101(2 * y_begin + 1, hs), xb, s0);
+            down_load_f32(plane, ps, reflect101(2 * y_begin + 2, hs), xb, s1);
+            for (int y = y_begin; y < y_end; ++y) {
+                down_row_f32(s0, o1);
+                down_row_f32(s1, e2);
+                if (y + 1 < y_end) {
+                    down_load_f32(plane, ps, reflect101(2 * y + 3, hs), xb, s0);
+                    down_load_f32(plane, ps, reflect101(2 * y + 4, hs), xb, s1);
                 }
                 f4_t ov;
+                float o[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    o[k] = ((((e1[k] * 6.0f + (o0[k] + o1[k]) * 4.0f) + e0[k]) + e2[k])) * (1.0f / 256.0f);
                 ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
-                if (j < ny) st_f4(dst + c * dplane + (size_t)j * po, ov);
+                st_f4(dst + c * dplane + (size_t)y * po, ov);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { e0[k] = e1[k]; o0[k] = o1[k]; e1[k] = e2[k]; }
             }
         }
     }
+}
+
+// The border columns of a level that k_down_march leaves out: outputs 0 .. 3 and 4 (ncg + 1) .. wo - 1 (at most 12
+// columns; every column when the level has no interior column group), one pixel per thread with the full border rule.
+template <int SRC>
+__global__ __launch_bounds__(256) void k_down_cols(const TileDev *__restrict__ tiles, const TileSrc *__restrict__ srcs,
+                                                   int lvl, int cn, float *__restrict__ arena,
+                                                   const float *__restrict__ luts)
+{
+    const TileDev &T = tiles[blockIdx.z];
+    if (lvl + 1 >= T.nl) return;
+    const int wo = T.W[lvl + 1];
+    const int ncg = down_ncg(T.W[lvl], wo);
+    const int e = threadIdx.x;
+    const int x = (ncg <= 0 || e < 4) ? e : 4 * (ncg + 1) + (e - 4);
+    const int y = T.g0[lvl + 1] + blockIdx.y * 16 + threadIdx.y;
+    if (x >= wo || y >= T.g1[lvl + 1]) return;
+    TileSrc S;
+    S.p = nullptr;
+    S.stride = 0;
+    if (SRC == SRC_U8 || SRC == SRC_F32) S = srcs[blockIdx.z];
+    down_pixel<SRC>(T, S, lvl, cn, x, y, arena, luts);
 }
 
 // R_i for one level of every tile:  top level: G*W;  else up(R_{i+1}) + (G_i - up(G_{i+1})) * W_i
@@ -2610,14 +2685,26 @@ static int blend_pyramids(sr_blend_plan *P, int dtype, void *const *h_d_tiles, c
         ProfScope ps(ctx, i == 0 ? "down_l0" : "down_l1p");
         const bool blk = (P->cn == 3 || P->cn == 1) && !(i == 0 && dtype != SR_U8);
         if (blk) {
-            dim3 grid((max_w[i + 1] + 255) / 256, (max_g[i + 1] + 7) / 8, n_idx);
-            if (i == 0) {
-                if (P->cn == 3) hipLaunchKernelGGL((k_down_blk<SRC_U8, 3>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, P->d_arena, P->d_luts);
-                else hipLaunchKernelGGL((k_down_blk<SRC_U8, 1>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, P->d_arena, P->d_luts);
-            } else {
-                if (P->cn == 3) hipLaunchKernelGGL((k_down_blk<SRC_PLANAR, 3>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, P->d_arena, P->d_luts);
-                else hipLaunchKernelGGL((k_down_blk<SRC_PLANAR, 1>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, P->d_arena, P->d_luts);
+            int max_cells = 0;
+            for (int k = 0; k < n_idx; ++k) {
+                const TileDev &T = P->tiles[idx[k]];
+                if (i + 1 >= T.nl || T.g1[i + 1] <= T.g0[i + 1]) continue;
+                const int nseg = (T.g1[i + 1] - T.g0[i + 1] + DM_ROWS - 1) / DM_ROWS;
+                max_cells = std::max(max_cells, down_ncg(T.W[i], T.W[i + 1]) * nseg);
             }
+            if (max_cells > 0) {
+                dim3 grid((max_cells + 255) / 256, 1, n_idx);
+                if (i == 0) {
+                    if (P->cn == 3) hipLaunchKernelGGL((k_down_march<SRC_U8, 3>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, P->d_arena);
+                    else hipLaunchKernelGGL((k_down_march<SRC_U8, 1>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, P->d_arena);
+                } else {
+                    if (P->cn == 3) hipLaunchKernelGGL((k_down_march<SRC_PLANAR, 3>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, P->d_arena);
+                    else hipLaunchKernelGGL((k_down_march<SRC_PLANAR, 1>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, P->d_arena);
+                }
+            }
+            dim3 cgrid(1, (max_g[i + 1] + 15) / 16, n_idx), cblock(16, 16);
+            if (i == 0) hipLaunchKernelGGL(k_down_cols<SRC_U8>, cgrid, cblock, 0, ctx->stream, d_tiles, d_srcs, i, P->cn, P->d_arena, P->d_luts);
+            else hipLaunchKernelGGL(k_down_cols<SRC_PLANAR>, cgrid, cblock, 0, ctx->stream, d_tiles, d_srcs, i, P->cn, P->d_arena, P->d_luts);
             continue;
         }
         dim3 grid((max_w[i + 1] + 63) / 64, (max_g[i + 1] + 3) / 4, n_idx);
