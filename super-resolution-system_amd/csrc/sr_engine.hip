@@ -347,13 +347,14 @@ __global__ __launch_bounds__(256) void k_down(const TileDev *__restrict__ tiles,
 
 // ---------------------------------------------------------------------------------------------
 // Column-marching pyrDown.  One thread owns 4 output columns (a "column group": output x0 = 4 * cg, input columns
-// 2 x0 - 2 .. 2 x0 + 8) and walks down DM_ROWS output rows: every input row is loaded once and its horizontal pass
+// 2 x0 - 2 .. 2 x0 + 8) and walks down seg_rows output rows: every input row is loaded once and its horizontal pass
 // evaluated once; the five row-pass results an output row needs (rows 2y-2 .. 2y+2) live in registers.  Row indices
 // go through REFLECT_101, so the top / bottom tile borders need no separate path.  Only "interior" column groups
 // (whole window inside the row: cg = 1 .. ncg) run here; the few border columns of a level go to k_down_cols.
 // Lanes are laid over (segment, column group) cells flattened per tile, so waves are full except the last one.
+// seg_rows (output rows per segment, chosen per launch): longer segments amortise the 3-row prologue, shorter ones
+// keep enough cells in flight on the small levels.
 // ---------------------------------------------------------------------------------------------
-#define DM_ROWS 16
 
 // number of interior column groups of a level: cg = 1 .. ncg
 __host__ __device__ __forceinline__ int down_ncg(int ws, int wo)
@@ -410,7 +411,7 @@ __device__ __forceinline__ void down_row_f32(const float (&s)[11], float (&h)[4]
 
 template <int SRC, int CN>
 __global__ __launch_bounds__(256) void k_down_march(const TileDev *__restrict__ tiles, const TileSrc *__restrict__ srcs,
-                                                    int lvl, float *__restrict__ arena)
+                                                    int lvl, int seg_rows, float *__restrict__ arena)
 {
     const TileDev &T = tiles[blockIdx.z];
     if (lvl + 1 >= T.nl) return;
@@ -418,11 +419,11 @@ __global__ __launch_bounds__(256) void k_down_march(const TileDev *__restrict__ 
     const int ya = T.g0[lvl + 1], yb = T.g1[lvl + 1];
     const int ncg = down_ncg(ws, wo);
     if (ncg <= 0 || yb <= ya) return;
-    const int nseg = (yb - ya + DM_ROWS - 1) / DM_ROWS;
+    const int nseg = (yb - ya + seg_rows - 1) / seg_rows;
     const int cell = blockIdx.x * 256 + threadIdx.y * 64 + threadIdx.x;
     if (cell >= ncg * nseg) return;
     const int seg = cell / ncg, x0 = (1 + cell - seg * ncg) * 4;
-    const int y_begin = ya + seg * DM_ROWS, y_end = min(y_begin + DM_ROWS, yb);
+    const int y_begin = ya + seg * seg_rows, y_end = min(y_begin + seg_rows, yb);
     const int po = T.P[lvl + 1];
     const size_t dplane = (size_t)T.H[lvl + 1] * po;
     float *dst = arena + T.g_off[lvl + 1] + x0;
@@ -2685,21 +2686,29 @@ static int blend_pyramids(sr_blend_plan *P, int dtype, void *const *h_d_tiles, c
         ProfScope ps(ctx, i == 0 ? "down_l0" : "down_l1p");
         const bool blk = (P->cn == 3 || P->cn == 1) && !(i == 0 && dtype != SR_U8);
         if (blk) {
-            int max_cells = 0;
-            for (int k = 0; k < n_idx; ++k) {
-                const TileDev &T = P->tiles[idx[k]];
-                if (i + 1 >= T.nl || T.g1[i + 1] <= T.g0[i + 1]) continue;
-                const int nseg = (T.g1[i + 1] - T.g0[i + 1] + DM_ROWS - 1) / DM_ROWS;
-                max_cells = std::max(max_cells, down_ncg(T.W[i], T.W[i + 1]) * nseg);
+            int max_cells = 0, seg_rows = 8;
+            for (int cand = 32; cand >= 8; cand /= 2) {       // longest segments that still give ~8 blocks per CU
+                long long total = 0;
+                max_cells = 0;
+                seg_rows = cand;
+                for (int k = 0; k < n_idx; ++k) {
+                    const TileDev &T = P->tiles[idx[k]];
+                    if (i + 1 >= T.nl || T.g1[i + 1] <= T.g0[i + 1]) continue;
+                    const int nseg = (T.g1[i + 1] - T.g0[i + 1] + cand - 1) / cand;
+                    const int cells = down_ncg(T.W[i], T.W[i + 1]) * nseg;
+                    max_cells = std::max(max_cells, cells);
+                    total += cells;
+                }
+                if (total >= 512 * 1024) break;
             }
             if (max_cells > 0) {
                 dim3 grid((max_cells + 255) / 256, 1, n_idx);
                 if (i == 0) {
-                    if (P->cn == 3) hipLaunchKernelGGL((k_down_march<SRC_U8, 3>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, P->d_arena);
-                    else hipLaunchKernelGGL((k_down_march<SRC_U8, 1>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, P->d_arena);
+                    if (P->cn == 3) hipLaunchKernelGGL((k_down_march<SRC_U8, 3>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, seg_rows, P->d_arena);
+                    else hipLaunchKernelGGL((k_down_march<SRC_U8, 1>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, seg_rows, P->d_arena);
                 } else {
-                    if (P->cn == 3) hipLaunchKernelGGL((k_down_march<SRC_PLANAR, 3>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, P->d_arena);
-                    else hipLaunchKernelGGL((k_down_march<SRC_PLANAR, 1>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, P->d_arena);
+                    if (P->cn == 3) hipLaunchKernelGGL((k_down_march<SRC_PLANAR, 3>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, seg_rows, P->d_arena);
+                    else hipLaunchKernelGGL((k_down_march<SRC_PLANAR, 1>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, seg_rows, P->d_arena);
                 }
             }
             dim3 cgrid(1, (max_g[i + 1] + 15) / 16, n_idx), cblock(16, 16);
