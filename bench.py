@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
 """bench.py -- megapixels/sec of tile + blend + QA on a synthetic 720p -> 200 MP job (BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 200MP|150MP|100MP|4MP]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 200MP|150MP|100MP|4MP|200MP-kd ...]
+                    [--mode strips|batch] [--pcie]
 
 One process per GPU (N > 1: launched by torch.distributed.run, RCCL over xGMI).  A "step" is one
 pass of the hot path over one synthetic image: overlap-tile extract of the 5x5 tile grid from the
 device-resident SR output, [exchange of tile rows between tile owners and strip owners],
 Laplacian-pyramid blend of the canvas strips, PSNR + SSIM (uniform-7, Gaussian-11 cropped,
 Gaussian-11 full-frame) of the canvas against the reference upscale, one all-reduce of the metric
-partial sums.  N > 1 splits the SAME image over the ranks (strong scaling).
+partial sums.  N > 1 splits the SAME image over the ranks (strong scaling; --mode strips, the default and the
+BASELINE metric).  --mode batch is BASELINE config 4: every rank runs the whole pipeline on its own image, no
+communication on the data path (weak scaling).  "-kd" workloads use the non-uniform k-d tiling of config 5.
 
 Prints ONE JSON line (rank 0).  ``value`` = canvas megapixels / max-over-ranks wall time per step,
 inputs already resident in HBM.  ``roofline`` describes the dominant kernel (HIP-event time measured
@@ -128,7 +131,12 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="200MP", choices=["4MP", "100MP", "150MP", "200MP"])
+    ap.add_argument("--workload", default="200MP",
+                    choices=["4MP", "100MP", "150MP", "200MP", "100MP-kd", "150MP-kd", "200MP-kd"])
+    ap.add_argument("--mode", default="strips", choices=["strips", "batch"],
+                    help="strips: one image over all ranks (strong scaling, the BASELINE metric); "
+                         "batch: one image per rank, no data-path communication (config 4, weak scaling)")
+    ap.add_argument("--pcie", action="store_true", help="also time host->device of the inputs and device->host of the canvas")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-kernel HIP-event timing")
     args = ap.parse_args()
@@ -168,9 +176,10 @@ def main() -> int:
     # ---- inputs, resident in HBM before the timed region ----------------------------------------
     # reference = whole-image bicubic upscale of the synthetic 720p source; image (the "SR output" the
     # tiles are cut from) = the same upscale of a slightly different noise draw, so PSNR is finite.
-    src_ref = synthetic_source()
+    batch = args.mode == "batch"
+    src_ref = synthetic_source(noise_seed_offset=rank if batch else 0)
     src_img = np.clip(src_ref.astype(np.int16) + np.random.default_rng(7).integers(-3, 4, src_ref.shape), 0, 255).astype(np.uint8)
-    pipe = dp.DevicePipeline(geo, rank, world, local_rank)
+    pipe = dp.DevicePipeline(geo, 0, 1, local_rank) if batch else dp.DevicePipeline(geo, rank, world, local_rank)
     ctx = pipe.ctx
     t_src = torch.from_numpy(np.stack([src_ref, src_img])).to(dev)
     reference = torch.empty((H, W * cn), dtype=torch.uint8, device=dev)
@@ -191,14 +200,19 @@ def main() -> int:
     if not args.no_prof:
         ctx.prof_enable(True)
         ctx.prof_reset()
+    # per-step device time (events on the stream the kernels run on): median / min beside the mean of the contract
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    evs[0].record()
+    for i in range(args.steps):
         pipe.step(image, reference)
+        evs[i + 1].record()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
     prof = {} if args.no_prof else ctx.prof_get()
     ctx.prof_enable(False)
 
@@ -208,6 +222,24 @@ def main() -> int:
     elapsed = float(t.item())
     metrics = pipe.metrics()
 
+    pcie = None
+    if args.pcie and rank == 0:
+        # the boundary's host-buffer variant: inputs uploaded, canvas downloaded (pinned host memory); never `value`
+        h_in = torch.empty((2, H, W * cn), dtype=torch.uint8).pin_memory()
+        h_out = torch.empty((H, W * cn), dtype=torch.uint8).pin_memory()
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        image.copy_(h_in[0], non_blocking=True)
+        reference.copy_(h_in[1], non_blocking=True)
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        h_out.copy_(pipe.canvas, non_blocking=True)
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        pcie = {"h2d_ms": round(1e3 * (tb - ta), 3), "h2d_GB": round(2 * H * W * cn / 1e9, 3),
+                "d2h_ms": round(1e3 * (tc - tb), 3), "d2h_GB": round(H * W * cn / 1e9, 3),
+                "note": "pinned host buffers, one copy engine; add to ms_per_step for the host-buffer boundary"}
+
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         mp = geo.canvas_pixels / 1e6
@@ -216,12 +248,13 @@ def main() -> int:
         for name, (ms, launches) in prof.items():
             per_step_ms = ms / args.steps
             b = alg.get(name)
-            share = 1.0 / world if world > 1 else 1.0     # each rank moves ~1/N of the bytes (+ halo)
+            share = 1.0 / world if (world > 1 and not batch) else 1.0     # each rank moves ~1/N of the bytes (+ halo)
             kernels[name] = {"ms_per_step": round(per_step_ms, 4), "launches_per_step": launches / args.steps,
                              "alg_GB": None if b is None else round(b * share / 1e9, 4),
                              "GBps": None if b is None or per_step_ms <= 0 else round(b * share / 1e9 / (per_step_ms / 1e3), 1)}
         roofline = None
         traffic = measured_traffic() if (world == 1 and args.workload == "200MP") else {}
+        images = world if batch else 1
         cands = [(v["ms_per_step"], k) for k, v in kernels.items() if v["alg_GB"] is not None]
         if cands:
             _, dom = max(cands)
@@ -241,14 +274,16 @@ def main() -> int:
         blend_ms = sum(v["ms_per_step"] for kk, v in kernels.items()
                        if kk in ("weight_down", "down_l0", "down_l1p", "up_level", "final_gather"))
         total_alg = sum(alg[kk] for kk in kernels if kk in alg)
+        div = world if (world > 1 and not batch) else 1          # strips: each rank moves ~1/N of the bytes
+        blend_alg = sum(alg[kk] for kk in ("down_l0", "down_l1p", "up_level", "final_gather")) / div
         out = {
             "metric": "megapixels/sec tile+blend+QA at 200MP, 1/2/4/8 GPU",
-            "value": round(mp / (elapsed / args.steps), 1),
+            "value": round(images * mp / (elapsed / args.steps), 1),
             "unit": "MP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "weak" if batch else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic" if backend == "nccl" else f"synthetic (REHEARSAL backend {backend}: not a measurement)",
@@ -256,14 +291,17 @@ def main() -> int:
                                    f"{len(geo.rects)} tiles {geo.rects[0][2]}x{geo.rects[0][3]}, {geo.levels}-level "
                                    f"Laplacian blend (cosine weights) + PSNR + SSIM(uniform7,gauss11,simple)",
                        "tile_pixels": geo.tile_pixels, "canvas_pixels": geo.canvas_pixels,
-                       "parallelism": f"strips{world}" if world > 1 else "single"},
+                       "parallelism": (f"batch{world}" if batch else f"strips{world}") if world > 1 else "single"},
+            "step_ms": {"median": round(step_ms[len(step_ms) // 2], 4), "min": round(step_ms[0], 4),
+                        "max": round(step_ms[-1], 4), "clock": "HIP events, rank 0"},
+            "pcie": pcie,
             "roofline": roofline,
             "kernels": kernels,
             "blend": {"ms_per_step": round(blend_ms, 4),
-                      "alg_GB": round(sum(alg[kk] for kk in ("down_l0", "down_l1p", "up_level", "final_gather")) / 1e9 / (world if world > 1 else 1), 3),
-                      "GBps": None if blend_ms <= 0 else round(sum(alg[kk] for kk in ("down_l0", "down_l1p", "up_level", "final_gather")) / 1e9 / (world if world > 1 else 1) / (blend_ms / 1e3), 1),
-                      "frac_of_peak": None if blend_ms <= 0 else round(sum(alg[kk] for kk in ("down_l0", "down_l1p", "up_level", "final_gather")) / 1e9 / (world if world > 1 else 1) / (blend_ms / 1e3) / HBM_PEAK_GBS, 4),
-                      "survey_model_GBps": None if blend_ms <= 0 else round(alg["_survey_blend_model"] / 1e9 / (world if world > 1 else 1) / (blend_ms / 1e3), 1)},
+                      "alg_GB": round(blend_alg / 1e9, 3),
+                      "GBps": None if blend_ms <= 0 else round(blend_alg / 1e9 / (blend_ms / 1e3), 1),
+                      "frac_of_peak": None if blend_ms <= 0 else round(blend_alg / 1e9 / (blend_ms / 1e3) / HBM_PEAK_GBS, 4),
+                      "survey_model_GBps": None if blend_ms <= 0 else round(alg["_survey_blend_model"] / div / 1e9 / (blend_ms / 1e3), 1)},
             "summary": {"gpu_kernel_ms_per_step": round(gpu_ms, 4), "blend_ms_per_step": round(blend_ms, 4),
                         "alg_GB_per_step": round(total_alg / 1e9, 3),
                         "blend_GBps_vs_survey_model": None if blend_ms <= 0 else
@@ -272,7 +310,8 @@ def main() -> int:
             "quality": {k: (v if np.isfinite(v) else str(v)) for k, v in metrics.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(src_ref, geo)
+            # the k-d workloads time the grid geometry of the same canvas (same pixels, same kernels on the CPU side)
+            out["cpu_baseline"] = cpu_baseline(src_ref, dp.workload_geometry(args.workload.replace("-kd", "")))
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -160,8 +160,9 @@ SR_API int sr_laplacian_blend(sr_blend_plan *plan, int dtype, void *const *h_d_t
                               const int64_t *h_strides, uint8_t *d_canvas, int64_t canvas_stride,
                               float *d_canvas_f32);
 /* The Laplacian blend in two stages, so a strip owner can overlap the row exchange with compute:
- * sr_blend_pyramids builds G_i / R_i for the listed tiles only (first != 0: also the weight pyramids; call it
- * first with the tiles already resident, then with the tiles that arrived), sr_blend_gather is the canvas gather
+ * sr_blend_pyramids builds G_i / R_i for the listed tiles only (first != 0: also the weight pyramids, which depend
+ * only on the plan and are built once and kept; call it first with the tiles already resident, then with the tiles
+ * that arrived), sr_blend_gather is the canvas gather
  * over all tiles.  sr_laplacian_blend == pyramids(all, first) + gather. */
 SR_API int sr_blend_pyramids(sr_blend_plan *plan, int dtype, void *const *h_d_tiles, const int64_t *h_strides,
                              const int *h_tile_idx, int n_idx, int first);

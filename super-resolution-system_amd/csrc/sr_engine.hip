@@ -1281,11 +1281,13 @@ __global__ __launch_bounds__(256) void k_tile_extract(const unsigned char *__res
     const long long row_bytes = (long long)D.out_w * cn;
     if (r >= D.out_h || b0 >= row_bytes) return;
     unsigned char *d = D.dst + (size_t)r * D.dstride + b0;
-    const bool dst_al = ((((size_t)D.dst) | (size_t)D.dstride) & 3) == 0;
-    if (r < D.h && b0 + 16 <= (long long)D.w * cn && dst_al) {
+    if (r < D.h && b0 + 16 <= (long long)D.w * cn) {
+        // 16 bytes at any source / destination alignment (tile x and width are arbitrary): the hardware splits an
+        // unaligned access; a dword-aligned destination row gets the aligned store
         const unsigned char *sp = img + (size_t)(D.y + r) * istride + (size_t)D.x * cn + b0;
         const u4_t v = *(const u4_a1_t *)sp;
-        *(u4_a4_t *)d = v;
+        if (((((size_t)D.dst) | (size_t)D.dstride) & 3) == 0) *(u4_a4_t *)d = v;
+        else *(u4_a1_t *)d = v;
         return;
     }
     const int nb = (int)min((long long)16, row_bytes - b0);
@@ -1979,6 +1981,7 @@ struct sr_blend_plan {
     int *d_edge_cand = nullptr;
     int n_edge_blocks = 0;
     int *d_cand_off = nullptr, *d_cand_idx = nullptr;   // per 256 x 8 block: candidate tiles (CSR, list order)
+    bool weights_ready = false;                         // weight pyramids of the classes are in the arena
     float *d_luts = nullptr;
     // launch extents per level
     int max_w[SR_MAX_LEVELS] = {0}, max_grows[SR_MAX_LEVELS] = {0}, max_rrows[SR_MAX_LEVELS] = {0};
@@ -2632,8 +2635,10 @@ static int blend_pyramids(sr_blend_plan *P, int dtype, void *const *h_d_tiles, c
     const int rows = P->row_end - P->row_begin;
     if (rows <= 0 || P->max_nl <= 1) return SR_OK;
     dim3 block(64, 4);
-    if (first) {
-        // weight pyramids: level 0 analytic (LUT) -> 1, then planar chain
+    if (first && !P->weights_ready) {
+        // weight pyramids: level 0 analytic (LUT) -> 1, then planar chain.  They depend only on the tile shapes and
+        // the row windows, both fixed per plan: built by the first blend, kept in the arena for every later one.
+        P->weights_ready = true;
         for (int i = 0; i + 1 < P->max_nl; ++i) {
             if (P->cmax_rows[i + 1] <= 0) continue;
             ProfScope ps(ctx, "weight_down");

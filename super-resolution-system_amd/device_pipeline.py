@@ -61,7 +61,38 @@ WORKLOADS = {
 }
 
 
+def kd_geometry(canvas_w: int, canvas_h: int, leaves: int = 32, overlap: float = 0.10, seed: int = 20260313,
+                levels: int = 6, weight_type: str = "cosine") -> Geometry:
+    """Non-uniform (content-aware style) tiling, BASELINE config 5 / SURVEY.md 8(d): a seeded k-d split of the canvas
+    into ``leaves`` boxes (largest box first, along its longer side, at 35-65 %), each grown by ``overlap`` of its own
+    size on every side and clipped to the canvas -- so neighbours overlap by at least 10 % and the rectangles are
+    what a caller would pass as ``TileInfo(x, y)`` (blending_module.py:96-112).  Row-major by (y, x)."""
+    rng = np.random.default_rng(seed)
+    boxes = [(0, 0, canvas_w, canvas_h)]
+    while len(boxes) < leaves:
+        i = max(range(len(boxes)), key=lambda k: (boxes[k][2] * boxes[k][3], -k))
+        x, y, w, h = boxes.pop(i)
+        f = float(rng.uniform(0.35, 0.65))
+        if w >= h:
+            c = min(max(int(w * f), 1), w - 1)
+            boxes += [(x, y, c, h), (x + c, y, w - c, h)]
+        else:
+            c = min(max(int(h * f), 1), h - 1)
+            boxes += [(x, y, w, c), (x, y + c, w, h - c)]
+    rects = []
+    for (x, y, w, h) in boxes:
+        mx, my = int(np.ceil(w * overlap)), int(np.ceil(h * overlap))
+        x0, y0 = max(x - mx, 0), max(y - my, 0)
+        x1, y1 = min(x + w + mx, canvas_w), min(y + h + my, canvas_h)
+        rects.append((x0, y0, x1 - x0, y1 - y0))
+    rects.sort(key=lambda r: (r[1], r[0]))
+    return Geometry(canvas_w, canvas_h, rects, 3, levels, weight_type)
+
+
 def workload_geometry(name: str) -> Geometry:
+    if name.endswith("-kd"):                      # e.g. "200MP-kd": same canvas, non-uniform rectangles
+        base = grid_geometry(**WORKLOADS[name[:-3]])
+        return kd_geometry(base.canvas_w, base.canvas_h)
     return grid_geometry(**WORKLOADS[name])
 
 

@@ -128,3 +128,23 @@ def test_exchange_plan_properties():
             assert max_pair(xp) <= min(max_pair(o) for o in others)      # the balanced policy has the lightest busiest link
         if world == 8:
             assert max(xp.bytes_received(r, geo) for r in range(8)) < 200e6
+
+
+def test_kd_geometry_covers_canvas_with_overlap():
+    """Config 5 tiling generator: deterministic, covers every canvas pixel, neighbours overlap, and the exchange plan
+    of a strip partition over it delivers every row a strip reads."""
+    import device_pipeline as dp
+    g = dp.kd_geometry(2000, 1500, leaves=16, overlap=0.10, seed=3)
+    assert g.rects == dp.kd_geometry(2000, 1500, leaves=16, overlap=0.10, seed=3).rects
+    cover = np.zeros((g.canvas_h, g.canvas_w), np.int32)
+    for (x, y, w, h) in g.rects:
+        assert x >= 0 and y >= 0 and x + w <= g.canvas_w and y + h <= g.canvas_h and w >= 16 and h >= 16
+        cover[y:y + h, x:x + w] += 1
+    assert cover.min() >= 1 and cover.max() >= 2
+    assert (cover >= 2).mean() > 0.2                      # >= 10 % margins on every side of every box
+    plan = dp.make_exchange_plan(g, 4)
+    for r in range(4):
+        for t in range(len(g.rects)):
+            a, b = plan.need[r][t]
+            if a < b and plan.owners[t] != r:
+                assert any(tt == t and aa <= a and bb >= b for (_, tt, aa, bb) in plan.recvs(r))

@@ -257,6 +257,65 @@ def test_full_size_200mp_properties():
     pipe.close()
 
 
+def test_device_pipeline_kd_tiling(rng):
+    """BASELINE config 5 geometry at test size: non-uniform k-d rectangles (odd origins, widths not a multiple of 4,
+    one weight class per tile) through the same pipeline object -- canvas and scores equal the oracle's."""
+    import torch
+    import device_pipeline as dp
+    geo = dp.kd_geometry(1037, 811, leaves=9, overlap=0.12, seed=5)
+    H, W = geo.canvas_h, geo.canvas_w
+    assert len({(w, h) for (_, _, w, h) in geo.rects}) > 4 and any(x % 2 for (x, _, _, _) in geo.rects)
+    image, reference = _img(rng, H, W), _img(rng, H, W)
+    pipe = dp.DevicePipeline(geo, 0, 1, 0)
+    t_img = torch.from_numpy(image.reshape(H, -1)).cuda()
+    t_ref = torch.from_numpy(reference.reshape(H, -1)).cuda()
+    for _ in range(2):                     # second step runs on the cached weight pyramids
+        pipe.step(t_img, t_ref)
+    torch.cuda.synchronize()
+    tiles = [np.ascontiguousarray(image[y:y + h, x:x + w]) for (x, y, w, h) in geo.rects]
+    for t, (x, y, w, h) in enumerate(geo.rects):
+        assert np.array_equal(pipe.local_tiles[t].cpu().numpy().reshape(h, w, 3), tiles[t])
+    ref_canvas = oc.laplacian_fusion(tiles, [(y, x) for (x, y, _, _) in geo.rects], (H, W), 6, "cosine")
+    assert np.array_equal(pipe.canvas.cpu().numpy().reshape(H, W, 3), ref_canvas)
+    m = pipe.metrics()
+    assert m["psnr"] == oc.psnr(reference, ref_canvas)
+    g0, g1 = oc.rgb2gray_u8(reference), oc.rgb2gray_u8(ref_canvas)
+    for mode in ("uniform", "gauss", "simple"):
+        assert m[f"ssim_{mode}"] == pytest.approx(oc.ssim(g0, g1, mode), rel=1e-9)
+    pipe.close()
+
+
+@pytest.mark.parametrize("world", [3, 8])
+def test_virtual_ranks_kd_tiling(rng, world):
+    """Strip partition of the non-uniform tiling: rehearsed ranks tile the monolithic canvas bit for bit."""
+    import torch
+    import device_pipeline as dp
+    geo = dp.kd_geometry(1290, 1130, leaves=11, overlap=0.10, seed=11)
+    H, W = geo.canvas_h, geo.canvas_w
+    image, reference = _img(rng, H, W), _img(rng, H, W)
+    t_img = torch.from_numpy(image.reshape(H, -1)).cuda()
+    t_ref = torch.from_numpy(reference.reshape(H, -1)).cuda()
+    mono = dp.DevicePipeline(geo, 0, 1, 0)
+    mono.step(t_img, t_ref)
+    torch.cuda.synchronize()
+    full_tiles = {t: mono.local_tiles[t].clone() for t in range(len(geo.rects))}
+    got = torch.zeros_like(mono.canvas)
+    sums = torch.zeros_like(mono.results)
+    for r in range(world):
+        p = dp.DevicePipeline(geo, r, world, 0)
+        p.rehearse_fill(full_tiles)
+        p.rehearse_step(t_ref)
+        torch.cuda.synchronize()
+        a, b = p.strip
+        got[a:b] = p.canvas[a:b]
+        sums += p.results
+        p.close()
+    assert torch.equal(got, mono.canvas)
+    assert float(sums[0]) == float(mono.results[0])
+    assert torch.allclose(sums[1:], mono.results[1:], rtol=1e-12, atol=0)
+    mono.close()
+
+
 @pytest.mark.parametrize("world", [2, 5, 8])
 def test_virtual_ranks_reproduce_single_gpu(rng, world):
     """Every rank of an N-GPU run rehearsed on one GPU (its own buffers, only the rows the exchange plan delivers,
