@@ -1522,9 +1522,9 @@ __global__ __launch_bounds__(256) void k_rgb2gray(const unsigned char *__restric
 //     frame with REFLECT_101 borders -> "simple" (branch B): scipy's gaussian_filter(sigma 1.5, truncate 3.5) and
 //     cv2.GaussianBlur((11,11), 1.5) are the same normalised kernel, the variants differ only in border and crop,
 //   * the uniform 7x7 SSIM map, entirely in integers (window sums are exact), fp64 only for the final formula.
-// fp64 throughout where the reference is (float64); the row pass works on exact integers: gray values, (x+y)^2 and
-// (x-y)^2 are ints, symmetric taps are pair-summed as ints and only 6 products per map are formed.  4 filtered maps
-// (x, y, (x+y)^2, (x-y)^2) replace the reference's 5:  uxx + uyy = (P + Q) / 2,  uxy = (P - Q) / 4.
+// fp64 throughout where the reference is (float64); the row pass works on exact integers: gray values, x^2 + y^2
+// and x*y are ints, symmetric taps are pair-summed as ints and only 6 products per map are formed.  4 filtered maps
+// (x, y, x^2 + y^2, x*y) replace the reference's 5: SSIM needs uxx and uyy only as their sum.
 // ---------------------------------------------------------------------------------------------
 enum { ASSESS_SSE = 1, ASSESS_UNIFORM = 2, ASSESS_GAUSS = 4, ASSESS_SIMPLE = 8, ASSESS_ALL_BITS = 15 };
 
@@ -1633,7 +1633,7 @@ __device__ __forceinline__ double fast_recip(double d)
 
 __device__ __forceinline__ double ssim_value(double ux, double uy, double spq, double dpq, double c1, double c2)
 {
-    // spq = (P + Q) / 2 = uxx + uyy,  dpq = (P - Q) / 4 = uxy
+    // spq = uxx + uyy,  dpq = uxy
     const double uxuy = ux * uy, uu = ux * ux + uy * uy;
     const double a1 = 2.0 * uxuy + c1, a2 = 2.0 * (dpq - uxuy) + c2;
     const double b1 = uu + c1, b2 = (spq - uu) + c2;
@@ -1694,9 +1694,8 @@ __global__ __launch_bounds__(256) void k_assess_march(const unsigned char *__res
                 // Opaque to the optimiser: with the values known to be zero-extended bytes, hipcc (ROCm 7.2) folded sums of
                 // byte products into v_perm_b32 + v_dot4_u32_u8 sequences that gave wrong sums (seen in an earlier kernel)
                 asm volatile("" : "+v"(xv[j]), "+v"(yv[j]));
-                const int sm = xv[j] + yv[j], df = xv[j] - yv[j];
-                pv[j] = __mul24(sm, sm);                         // |sm| <= 510: full-rate 24-bit multiply
-                qv[j] = __mul24(df, df);
+                pv[j] = __mul24(xv[j], xv[j]) + __mul24(yv[j], yv[j]);     // x^2 + y^2  (one mul + one mad)
+                qv[j] = __mul24(xv[j], yv[j]);                              // x * y
             }
             if (do_g) {
                 double hx = (double)xv[5] * P.k[0], hy = (double)yv[5] * P.k[0];
@@ -1727,8 +1726,8 @@ __global__ __launch_bounds__(256) void k_assess_march(const unsigned char *__res
                 const int orow = r - 8, my = by0 + orow;             // window rows r-6 .. r, centre r-3
                 if (orow >= 0 && orow < AM_TY && my < P.ry1 && my >= 3 && my < P.h - 3 && u_col) {
                     const double mux = (double)(t_xy & 0xFFFF) * inv49, muy = (double)((unsigned)t_xy >> 16) * inv49;
-                    const double sxxyy = (double)((t_p + t_q) >> 1) * inv49;     // (sum xx + sum yy) / 49, exact integers
-                    const double sxy = (double)((t_p - t_q) >> 2) * inv49;       // sum xy / 49
+                    const double sxxyy = (double)t_p * inv49;                    // (sum xx + sum yy) / 49, exact integers
+                    const double sxy = (double)t_q * inv49;                      // sum xy / 49
                     const double uxuy = mux * muy, uu = mux * mux + muy * muy;
                     const double a1 = 2.0 * uxuy + P.c1a, a2 = 2.0 * (cn49 * (sxy - uxuy)) + P.c2a;
                     const double b1 = uu + P.c1a, b2 = cn49 * (sxxyy - uu) + P.c2a;
@@ -1747,7 +1746,7 @@ __global__ __launch_bounds__(256) void k_assess_march(const unsigned char *__res
                             acc = fma(f[m][(s + 6 + 11 - j) % 11] + f[m][(s + 6 + j) % 11], P.k[j], acc);
                         u[m] = acc;
                     }
-                    const double spq = 0.5 * (u[2] + u[3]), dpq = 0.25 * (u[2] - u[3]);
+                    const double spq = u[2], dpq = u[3];
                     const bool interior = my >= AM_R && my < P.h - AM_R && g_col;
                     if (P.same_c) {
                         const double sv = ssim_value(u[0], u[1], spq, dpq, P.c1a, P.c2a);
