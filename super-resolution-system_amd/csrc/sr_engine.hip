@@ -1562,66 +1562,6 @@ __device__ __forceinline__ void load_gray_pair(const unsigned char *__restrict__
 }
 
 
-// Gray halo tile of both images into LDS, four pixels per thread step (one 12-byte load per image for RGB,
-// one 4-byte load for gray input); groups that leave the image take the per-pixel REFLECT_101 path.
-// Returns this thread's share of the squared differences of the block's interior pixels.
-template <int CN, int ROWS, int COLS4, int GP, int R, int TX, int TY>
-__device__ __forceinline__ unsigned long long load_gray_tile(const unsigned char *__restrict__ a, long long sa,
-                                                             const unsigned char *__restrict__ b, long long sb,
-                                                             int h, int w, int shift, int ry1, bool want_sse, int bx0,
-                                                             int by0, unsigned char (*gxs)[GP], unsigned char (*gys)[GP])
-{
-    unsigned long long sse = 0;
-    for (int i = threadIdx.x; i < ROWS * COLS4; i += 256) {
-        const int ly = i / COLS4, lx = (i - ly * COLS4) * 4;
-        const int gy = by0 - R + ly, gx = bx0 - R + lx;
-        const int sy = reflect101(gy, h);
-        int ga[4], gb[4];
-        unsigned sq[4];
-        if (gx >= 0 && gx + 3 < w) {
-            const unsigned char *pa = a + (size_t)sy * sa + (size_t)gx * CN;
-            const unsigned char *pb = b + (size_t)sy * sb + (size_t)gx * CN;
-            if (CN == 3) {
-                const u3_t qa = ld_u3_a1(pa), qb = ld_u3_a1(pb);
-                const unsigned wa[3] = {qa.x, qa.y, qa.z}, wb[3] = {qb.x, qb.y, qb.z};
-                int ca[12], cb[12];
-#pragma unroll
-                for (int t = 0; t < 12; ++t) {
-                    ca[t] = (int)((wa[t >> 2] >> (8 * (t & 3))) & 0xFFu);
-                    cb[t] = (int)((wb[t >> 2] >> (8 * (t & 3))) & 0xFFu);
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    ga[k] = gray_rgb(ca[3 * k], ca[3 * k + 1], ca[3 * k + 2], shift);
-                    gb[k] = gray_rgb(cb[3 * k], cb[3 * k + 1], cb[3 * k + 2], shift);
-                    const int dr = ca[3 * k] - cb[3 * k], dg = ca[3 * k + 1] - cb[3 * k + 1], db = ca[3 * k + 2] - cb[3 * k + 2];
-                    sq[k] = (unsigned)(dr * dr + dg * dg + db * db);
-                }
-            } else {
-                const unsigned qa = *(const u1_a1_t *)pa, qb = *(const u1_a1_t *)pb;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    ga[k] = (int)((qa >> (8 * k)) & 0xFFu);
-                    gb[k] = (int)((qb >> (8 * k)) & 0xFFu);
-                    const int d = ga[k] - gb[k];
-                    sq[k] = (unsigned)(d * d);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) load_gray_pair<CN>(a, sa, b, sb, sy, reflect101(gx + k, w), shift, ga[k], gb[k], sq[k]);
-        }
-        *(unsigned *)&gxs[ly][lx] = (unsigned)ga[0] | ((unsigned)ga[1] << 8) | ((unsigned)ga[2] << 16) | ((unsigned)ga[3] << 24);
-        *(unsigned *)&gys[ly][lx] = (unsigned)gb[0] | ((unsigned)gb[1] << 8) | ((unsigned)gb[2] << 16) | ((unsigned)gb[3] << 24);
-        if (want_sse && ly >= R && ly < R + TY && gy < ry1 && gy < h) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (lx + k >= R && lx + k < R + TX && gx + k < w) sse += sq[k];
-        }
-    }
-    return sse;
-}
-
 // 1 / d to full double precision without the IEEE division sequence (d is a product of positive SSIM terms)
 __device__ __forceinline__ double fast_recip(double d)
 {
@@ -1642,32 +1582,111 @@ __device__ __forceinline__ double ssim_value(double ux, double uy, double spq, d
 
 // ---------------------------------------------------------------------------------------------
 // k_assess_march: all four metrics in ONE pass, column-marching.  A block is 256 columns wide (768 B of RGB per
-// row: whole cache lines, ~4 % column halo) and AM_TY rows tall.  After the gray halo tile is in LDS each thread owns
-// one column and walks down the rows: the row pass of its column (integer pair sums, 6 fp64 products per map) goes
-// into an 11-deep register FIFO, the column pass reads the FIFO (static indices: the row loop is unrolled by 11), so
-// the filtered maps never touch LDS and there is no barrier after the load phase.  The uniform-7 variant rides
-// along: its per-row 7-tap integer sums go through a 7-slot per-column ring in LDS, the 7x7 sums slide in registers.
+// row: whole cache lines, ~4 % column halo) and walks down AM_TY + 10 rows in chunks of 11.  Per chunk the block
+// converts 11 rows of both images to gray once per pixel and leaves, per pixel, three dwords in LDS: x | y << 16,
+// x*y and x^2 + y^2 (so no thread ever recomputes a neighbour's products, and one packed add pair-sums x and y
+// together).  Then each thread owns one column: the row pass of its column (integer pair sums, 6 fp64 products per
+// map) goes into an 11-deep register FIFO, the column pass reads the FIFO with static indices (the chunk loop body
+// is the 11 unrolled rows), so the filtered maps never touch LDS.  The FIFO and the 7x7 window sums carry over
+// from chunk to chunk: the only recomputed halo is the 10 rows at the top of a block (8 %).  The uniform-7 variant
+// rides along: its per-row 7-tap integer sums go through a 7-slot per-column ring in LDS.
 // ---------------------------------------------------------------------------------------------
 #define AM_TX 256
-#define AM_TY 62
 #define AM_R 5
-#define AM_ROWS (AM_TY + 2 * AM_R) /* 72: gray tile + ring = 53 KB -> 3 blocks per CU */
-#define AM_GP 272                   /* gray row pitch: 68 groups of 4 pixels */
+#define AM_GP 272                       /* row pitch in pixels: 68 groups of 4 */
+#define AM_CH 11                        /* rows per chunk == FIFO depth */
+#define AM_NCH 12                       /* chunks per block */
+#define AM_ROWS (AM_CH * AM_NCH)        /* 132 rows marched */
+#define AM_TY (AM_ROWS - 2 * AM_R)      /* 122 output rows per block; LDS 36 KB + 14 KB ring -> 3 blocks per CU */
+
+// gray conversion + per-pixel products of 4-pixel groups of chunk `ch` into LDS; returns this thread's share of the
+// squared differences of the block's own pixels
+template <int CN>
+__device__ __forceinline__ unsigned long long assess_load_chunk(const unsigned char *__restrict__ a, long long sa,
+                                                                const unsigned char *__restrict__ b, long long sb,
+                                                                const AssessParams &P, int bx0, int by0, int ch,
+                                                                int rows_needed, unsigned (*XY)[AM_GP],
+                                                                unsigned (*QQ)[AM_GP], unsigned (*PP)[AM_GP])
+{
+    unsigned long long sse = 0;
+    const bool want_sse = (P.flags & ASSESS_SSE) != 0;
+    for (int i = threadIdx.x; i < AM_CH * (AM_GP / 4); i += 256) {
+        const int ly = i / (AM_GP / 4), lx = (i - ly * (AM_GP / 4)) * 4;
+        const int lr = ch * AM_CH + ly;
+        if (lr >= rows_needed) break;                       // rows grow with i
+        const int gy = by0 - AM_R + lr, gx = bx0 - AM_R + lx;
+        const int sy = reflect101(gy, P.h);
+        int ga[4], gb[4];
+        unsigned sq[4];
+        if (gx >= 0 && gx + 3 < P.w) {
+            const unsigned char *pa = a + (size_t)sy * sa + (size_t)gx * CN;
+            const unsigned char *pb = b + (size_t)sy * sb + (size_t)gx * CN;
+            if (CN == 3) {
+                const u3_t qa = ld_u3_a1(pa), qb = ld_u3_a1(pb);
+                const unsigned wa[3] = {qa.x, qa.y, qa.z}, wb[3] = {qb.x, qb.y, qb.z};
+                int ca[12], cb[12];
+#pragma unroll
+                for (int t = 0; t < 12; ++t) {
+                    ca[t] = (int)((wa[t >> 2] >> (8 * (t & 3))) & 0xFFu);
+                    cb[t] = (int)((wb[t >> 2] >> (8 * (t & 3))) & 0xFFu);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    ga[k] = gray_rgb(ca[3 * k], ca[3 * k + 1], ca[3 * k + 2], P.shift);
+                    gb[k] = gray_rgb(cb[3 * k], cb[3 * k + 1], cb[3 * k + 2], P.shift);
+                    const int dr = ca[3 * k] - cb[3 * k], dg = ca[3 * k + 1] - cb[3 * k + 1], db = ca[3 * k + 2] - cb[3 * k + 2];
+                    sq[k] = (unsigned)(dr * dr + dg * dg + db * db);
+                }
+            } else {
+                const unsigned qa = *(const u1_a1_t *)pa, qb = *(const u1_a1_t *)pb;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    ga[k] = (int)((qa >> (8 * k)) & 0xFFu);
+                    gb[k] = (int)((qb >> (8 * k)) & 0xFFu);
+                    const int d = ga[k] - gb[k];
+                    sq[k] = (unsigned)(d * d);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) load_gray_pair<CN>(a, sa, b, sb, sy, reflect101(gx + k, P.w), P.shift, ga[k], gb[k], sq[k]);
+        }
+        u4_t vxy, vq, vp;
+        unsigned txy[4], tq[4], tp[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            txy[k] = (unsigned)ga[k] | ((unsigned)gb[k] << 16);
+            tq[k] = (unsigned)__mul24(ga[k], gb[k]);
+            tp[k] = (unsigned)(__mul24(ga[k], ga[k]) + __mul24(gb[k], gb[k]));
+        }
+        vxy.x = txy[0]; vxy.y = txy[1]; vxy.z = txy[2]; vxy.w = txy[3];
+        vq.x = tq[0]; vq.y = tq[1]; vq.z = tq[2]; vq.w = tq[3];
+        vp.x = tp[0]; vp.y = tp[1]; vp.z = tp[2]; vp.w = tp[3];
+        *(u4_t *)&XY[ly][lx] = vxy;
+        *(u4_t *)&QQ[ly][lx] = vq;
+        *(u4_t *)&PP[ly][lx] = vp;
+        if (want_sse && lr >= AM_R && lr < AM_R + AM_TY && gy < P.ry1 && gy < P.h) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (lx + k >= AM_R && lx + k < AM_R + AM_TX && gx + k < P.w) sse += sq[k];
+        }
+    }
+    return sse;
+}
 
 template <int CN>
 __global__ __launch_bounds__(256) void k_assess_march(const unsigned char *__restrict__ a, long long sa,
                                                       const unsigned char *__restrict__ b, long long sb,
                                                       AssessParams P, double *__restrict__ part)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char gxs[AM_ROWS][AM_GP];
-    __shared__ __attribute__((aligned(16))) unsigned char gys[AM_ROWS][AM_GP];
-    __shared__ int U[7][2][AM_TX];      // per-row 7-tap sums, 62 bits packed: {sx:11, sy:11, sq lo:10}, {sp:21, sq hi:9}
+    __shared__ __attribute__((aligned(16))) unsigned XY[AM_CH][AM_GP];   // x | y << 16
+    __shared__ __attribute__((aligned(16))) unsigned QQ[AM_CH][AM_GP];   // x * y
+    __shared__ __attribute__((aligned(16))) unsigned PP[AM_CH][AM_GP];   // x^2 + y^2
+    __shared__ int U[7][2][AM_TX];      // per-row 7-tap sums, 61 bits packed: {sx:11, sy:11, sq lo:10}, {sp:21, sq hi:9}
     __shared__ double red[4][4];
     const int c = threadIdx.x;
     const int bx0 = blockIdx.x * AM_TX, by0 = P.ry0 + blockIdx.y * AM_TY;
-    const unsigned long long sse = load_gray_tile<CN, AM_ROWS, AM_GP / 4, AM_GP, AM_R, AM_TX, AM_TY>(
-        a, sa, b, sb, P.h, P.w, P.shift, P.ry1, (P.flags & ASSESS_SSE) != 0, bx0, by0, gxs, gys);
-    __syncthreads();
+    const int rows_needed = min(AM_TY, P.ry1 - by0) + 2 * AM_R;          // block-uniform
     const int mx = bx0 + c;
     const bool col_ok = mx < P.w;
     const bool do_u = (P.flags & ASSESS_UNIFORM) != 0, do_g = (P.flags & (ASSESS_GAUSS | ASSESS_SIMPLE)) != 0;
@@ -1679,85 +1698,87 @@ __global__ __launch_bounds__(256) void k_assess_march(const unsigned char *__res
         for (int i = 0; i < 11; ++i) f[m][i] = 0.0;
     int t_xy = 0, t_p = 0, t_q = 0;
     double sum_int = 0.0, sum_all = 0.0, sum_u = 0.0;
+    unsigned long long sse = 0;
     const double inv49 = 1.0 / 49.0, cn49 = 49.0 / 48.0;
+    int slot = 0;                                                       // row index mod 7
 #pragma unroll 1
-    for (int base = 0; base < AM_ROWS; base += 11) {
+    for (int ch = 0; ch < AM_NCH; ++ch) {
+        if (ch * AM_CH >= rows_needed) break;
+        __syncthreads();                                                // the previous chunk has been read
+        sse += assess_load_chunk<CN>(a, sa, b, sb, P, bx0, by0, ch, rows_needed, XY, QQ, PP);
+        __syncthreads();
 #pragma unroll
-        for (int s = 0; s < 11; ++s) {
-            const int r = base + s;
-            if (r < AM_ROWS) {
-            int xv[11], yv[11], pv[11], qv[11];
+        for (int s = 0; s < AM_CH; ++s) {
+            const int r = ch * AM_CH + s;
+            if (r < rows_needed) {
+                unsigned xy[11], qv[11], pv[11];
 #pragma unroll
-            for (int j = 0; j < 11; ++j) {
-                xv[j] = gxs[r][c + j];
-                yv[j] = gys[r][c + j];
-                // Opaque to the optimiser: with the values known to be zero-extended bytes, hipcc (ROCm 7.2) folded sums of
-                // byte products into v_perm_b32 + v_dot4_u32_u8 sequences that gave wrong sums (seen in an earlier kernel)
-                asm volatile("" : "+v"(xv[j]), "+v"(yv[j]));
-                pv[j] = __mul24(xv[j], xv[j]) + __mul24(yv[j], yv[j]);     // x^2 + y^2  (one mul + one mad)
-                qv[j] = __mul24(xv[j], yv[j]);                              // x * y
-            }
-            if (do_g) {
-                double hx = (double)xv[5] * P.k[0], hy = (double)yv[5] * P.k[0];
-                double hp = (double)pv[5] * P.k[0], hq = (double)qv[5] * P.k[0];
-#pragma unroll
-                for (int j = 1; j <= AM_R; ++j) {
-                    hx = fma((double)(xv[5 - j] + xv[5 + j]), P.k[j], hx);
-                    hy = fma((double)(yv[5 - j] + yv[5 + j]), P.k[j], hy);
-                    hp = fma((double)(pv[5 - j] + pv[5 + j]), P.k[j], hp);
-                    hq = fma((double)(qv[5 - j] + qv[5 + j]), P.k[j], hq);
+                for (int j = 0; j < 11; ++j) {
+                    xy[j] = XY[s][c + j];
+                    qv[j] = QQ[s][c + j];
+                    pv[j] = PP[s][c + j];
                 }
-                f[0][s] = hx; f[1][s] = hy; f[2][s] = hp; f[3][s] = hq;
-            }
-            if (do_u) {
-                int ux = 0, uy = 0, up = 0, uq = 0;
+                if (do_g) {
+                    double hx = (double)(xy[5] & 0xFFFFu) * P.k[0], hy = (double)(xy[5] >> 16) * P.k[0];
+                    double hp = (double)pv[5] * P.k[0], hq = (double)qv[5] * P.k[0];
 #pragma unroll
-                for (int j = 2; j <= 8; ++j) { ux += xv[j]; uy += yv[j]; up += pv[j]; uq += qv[j]; }
-                const int slot = r % 7;
-                if (r >= 7) {
-                    const unsigned o0 = (unsigned)U[slot][0][c], o1 = (unsigned)U[slot][1][c];
-                    t_xy -= (int)((o0 & 0x7FFu) | (((o0 >> 11) & 0x7FFu) << 16));
-                    t_p -= (int)(o1 & 0x1FFFFFu);
-                    t_q -= (int)((o0 >> 22) | ((o1 >> 21) << 10));
-                }
-                t_xy += ux | (uy << 16); t_p += up; t_q += uq;
-                U[slot][0][c] = (int)((unsigned)ux | ((unsigned)uy << 11) | (((unsigned)uq & 0x3FFu) << 22));
-                U[slot][1][c] = (int)((unsigned)up | (((unsigned)uq >> 10) << 21));
-                const int orow = r - 8, my = by0 + orow;             // window rows r-6 .. r, centre r-3
-                if (orow >= 0 && orow < AM_TY && my < P.ry1 && my >= 3 && my < P.h - 3 && u_col) {
-                    const double mux = (double)(t_xy & 0xFFFF) * inv49, muy = (double)((unsigned)t_xy >> 16) * inv49;
-                    const double sxxyy = (double)t_p * inv49;                    // (sum xx + sum yy) / 49, exact integers
-                    const double sxy = (double)t_q * inv49;                      // sum xy / 49
-                    const double uxuy = mux * muy, uu = mux * mux + muy * muy;
-                    const double a1 = 2.0 * uxuy + P.c1a, a2 = 2.0 * (cn49 * (sxy - uxuy)) + P.c2a;
-                    const double b1 = uu + P.c1a, b2 = cn49 * (sxxyy - uu) + P.c2a;
-                    sum_u += (a1 * a2) * fast_recip(b1 * b2);
-                }
-            }
-            if (do_g && r >= 2 * AM_R) {
-                const int orow = r - 2 * AM_R, my = by0 + orow;      // rows r-10 .. r are in the FIFO, centre r-5
-                if (orow < AM_TY && my < P.ry1 && my < P.h && col_ok) {
-                    double u[4];
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        double acc = f[m][(s + 6) % 11] * P.k[0];
-#pragma unroll
-                        for (int j = 1; j <= AM_R; ++j)
-                            acc = fma(f[m][(s + 6 + 11 - j) % 11] + f[m][(s + 6 + j) % 11], P.k[j], acc);
-                        u[m] = acc;
+                    for (int j = 1; j <= AM_R; ++j) {
+                        const unsigned sxy = xy[5 - j] + xy[5 + j];     // both pair sums in one add (each < 2^16)
+                        hx = fma((double)(sxy & 0xFFFFu), P.k[j], hx);
+                        hy = fma((double)(sxy >> 16), P.k[j], hy);
+                        hp = fma((double)(pv[5 - j] + pv[5 + j]), P.k[j], hp);
+                        hq = fma((double)(qv[5 - j] + qv[5 + j]), P.k[j], hq);
                     }
-                    const double spq = u[2], dpq = u[3];
-                    const bool interior = my >= AM_R && my < P.h - AM_R && g_col;
-                    if (P.same_c) {
-                        const double sv = ssim_value(u[0], u[1], spq, dpq, P.c1a, P.c2a);
-                        sum_all += sv;
-                        if (interior) sum_int += sv;
-                    } else {
-                        if (P.flags & ASSESS_SIMPLE) sum_all += ssim_value(u[0], u[1], spq, dpq, P.c1b, P.c2b);
-                        if (interior && (P.flags & ASSESS_GAUSS)) sum_int += ssim_value(u[0], u[1], spq, dpq, P.c1a, P.c2a);
+                    f[0][s] = hx; f[1][s] = hy; f[2][s] = hp; f[3][s] = hq;
+                }
+                if (do_u) {
+                    unsigned uxy = 0, up = 0, uq = 0;
+#pragma unroll
+                    for (int j = 2; j <= 8; ++j) { uxy += xy[j]; up += pv[j]; uq += qv[j]; }
+                    if (r >= 7) {
+                        const unsigned o0 = (unsigned)U[slot][0][c], o1 = (unsigned)U[slot][1][c];
+                        t_xy -= (int)((o0 & 0x7FFu) | (((o0 >> 11) & 0x7FFu) << 16));
+                        t_p -= (int)(o1 & 0x1FFFFFu);
+                        t_q -= (int)((o0 >> 22) | ((o1 >> 21) << 10));
+                    }
+                    t_xy += (int)uxy; t_p += (int)up; t_q += (int)uq;
+                    U[slot][0][c] = (int)((uxy & 0x7FFu) | ((uxy >> 16) << 11) | ((uq & 0x3FFu) << 22));
+                    U[slot][1][c] = (int)(up | ((uq >> 10) << 21));
+                    const int orow = r - 8, my = by0 + orow;             // window rows r-6 .. r, centre r-3
+                    if (orow >= 0 && orow < AM_TY && my < P.ry1 && my >= 3 && my < P.h - 3 && u_col) {
+                        const double mux = (double)(t_xy & 0xFFFF) * inv49, muy = (double)((unsigned)t_xy >> 16) * inv49;
+                        const double sxxyy = (double)t_p * inv49;                    // (sum xx + sum yy) / 49, exact integers
+                        const double sxy = (double)t_q * inv49;                      // sum xy / 49
+                        const double uxuy = mux * muy, uu = mux * mux + muy * muy;
+                        const double a1 = 2.0 * uxuy + P.c1a, a2 = 2.0 * (cn49 * (sxy - uxuy)) + P.c2a;
+                        const double b1 = uu + P.c1a, b2 = cn49 * (sxxyy - uu) + P.c2a;
+                        sum_u += (a1 * a2) * fast_recip(b1 * b2);
                     }
                 }
-            }
+                if (do_g && r >= 2 * AM_R) {
+                    const int orow = r - 2 * AM_R, my = by0 + orow;      // rows r-10 .. r are in the FIFO, centre r-5
+                    if (orow < AM_TY && my < P.ry1 && my < P.h && col_ok) {
+                        double u[4];
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) {
+                            double acc = f[m][(s + 6) % 11] * P.k[0];
+#pragma unroll
+                            for (int j = 1; j <= AM_R; ++j)
+                                acc = fma(f[m][(s + 6 + 11 - j) % 11] + f[m][(s + 6 + j) % 11], P.k[j], acc);
+                            u[m] = acc;
+                        }
+                        const bool interior = my >= AM_R && my < P.h - AM_R && g_col;
+                        if (P.same_c) {
+                            const double sv = ssim_value(u[0], u[1], u[2], u[3], P.c1a, P.c2a);
+                            sum_all += sv;
+                            if (interior) sum_int += sv;
+                        } else {
+                            if (P.flags & ASSESS_SIMPLE) sum_all += ssim_value(u[0], u[1], u[2], u[3], P.c1b, P.c2b);
+                            if (interior && (P.flags & ASSESS_GAUSS)) sum_int += ssim_value(u[0], u[1], u[2], u[3], P.c1a, P.c2a);
+                        }
+                    }
+                }
+                slot = slot == 6 ? 0 : slot + 1;
             }
         }
     }
