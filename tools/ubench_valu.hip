@@ -1,4 +1,5 @@
 // instruction-throughput microbenchmarks (gfx950): cycles per wave-instruction per SIMD
+// build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o ubench_valu tools/ubench_valu.hip   (run on the GPU box)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
