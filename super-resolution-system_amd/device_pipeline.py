@@ -257,7 +257,7 @@ class DevicePipeline:
     RESULT_FIELDS = ("sse", "ssim_uniform_sum", "ssim_gauss_sum", "ssim_simple_sum")
 
     def __init__(self, geo: Geometry, rank: int = 0, world: int = 1, device: Optional[int] = None,
-                 group=None, ssim_modes: Sequence[str] = ("uniform", "gauss", "simple")):
+                 group=None, ssim_modes: Sequence[str] = ("uniform", "gauss", "simple"), depth: int = 2):
         import torch
         self.torch = torch
         self.geo, self.rank, self.world, self.group = geo, rank, world, group
@@ -271,65 +271,87 @@ class DevicePipeline:
         self.strip = (self.xplan.bounds[rank], self.xplan.bounds[rank + 1])
         cn = geo.cn
         u8 = dict(dtype=torch.uint8, device=self.dev)
-        # tiles this rank owns (dense) and the row windows it receives of the others
         self.owned = [t for t, o in enumerate(self.xplan.owners) if o == rank]
-        self.local_tiles = {t: torch.empty((geo.rects[t][3], geo.rects[t][2] * cn), **u8) for t in self.owned}
-        self.recv_bufs = {t: torch.empty((b - a, geo.rects[t][2] * cn), **u8)
-                          for (_, t, a, b) in self.xplan.recvs(rank)}
+        need = self.xplan.need[rank]
+        self._local_needed = [t for t in range(len(geo.rects)) if need[t][0] < need[t][1] and t in self.owned]
+        self._remote_needed = [t for t in range(len(geo.rects)) if need[t][0] < need[t][1] and t not in self.owned]
+        self._strides = [w * cn for (_, _, w, _) in geo.rects]
+        # Buffer sets: the tiles this rank owns (dense), the row windows it receives of the others, the per-tile
+        # (virtual) base pointers for the blend and the metric partial sums.  Two sets when the exchange of the next
+        # image is to overlap the blend of the current one (pipeline_* below); step() uses set 0 only.
+        self.sets = []
+        for _ in range(max(1, depth if world > 1 else 1)):
+            local = {t: torch.empty((geo.rects[t][3], geo.rects[t][2] * cn), **u8) for t in self.owned}
+            recv = {t: torch.empty((b - a, geo.rects[t][2] * cn), **u8) for (_, t, a, b) in self.xplan.recvs(rank)}
+            ptrs = []
+            for t in range(len(geo.rects)):
+                a, b = need[t]
+                if a >= b:
+                    ptrs.append(0)
+                elif t in local:
+                    ptrs.append(local[t].data_ptr())
+                else:
+                    ptrs.append(recv[t].data_ptr() - a * self._strides[t])   # virtual row 0
+            self.sets.append(dict(local=local, recv=recv, ptrs=ptrs,
+                                  results=torch.zeros(4, dtype=torch.float64, device=self.dev)))
         self.canvas = torch.zeros((geo.canvas_h, geo.canvas_w * cn), **u8)
-        self.results = torch.zeros(4, dtype=torch.float64, device=self.dev)   # sr_assess_sums
         self.plan = _native.BlendPlan(self.ctx, geo.rects, cn, geo.canvas_h, geo.canvas_w, geo.levels,
                                       geo.weight_type, self.row_begin, self.row_end)
-        # per-tile (virtual) base pointers and strides for the blend
-        self._ptrs, self._strides = [], []
-        self._local_needed = [t for t in range(len(geo.rects))
-                              if self.xplan.need[rank][t][0] < self.xplan.need[rank][t][1] and t in self.local_tiles]
-        self._remote_needed = [t for t in range(len(geo.rects))
-                               if self.xplan.need[rank][t][0] < self.xplan.need[rank][t][1] and t not in self.local_tiles]
-        for t, (x, y, w, h) in enumerate(geo.rects):
-            stride = w * cn
-            a, b = self.xplan.need[rank][t]
-            if a >= b:
-                self._ptrs.append(0)
-            elif t in self.local_tiles:
-                self._ptrs.append(self.local_tiles[t].data_ptr())
-            else:
-                self._ptrs.append(self.recv_bufs[t].data_ptr() - a * stride)   # virtual row 0
-            self._strides.append(stride)
+        self._cur = 0                 # buffer set of the step in progress
+        self._pending = None          # exchange work handles of the set in progress (pipeline_*)
+        self._reduce_work = []
+        self._done = 0                # buffer set holding the last finished step's sums
+
+    # set 0 under the names the single-step path and the tests use
+    @property
+    def local_tiles(self):
+        return self.sets[0]["local"]
+
+    @property
+    def recv_bufs(self):
+        return self.sets[0]["recv"]
+
+    @property
+    def results(self):
+        return self.sets[self._done]["results"]
+
+    @property
+    def _ptrs(self):
+        return self.sets[0]["ptrs"]
 
     # -- stages ---------------------------------------------------------------------------------
-    def stage_tile(self, image):
+    def stage_tile(self, image, k: int = 0):
         """Overlap-tile extract of the tiles this rank owns (tiling_module.py:713-715 slice)."""
         if not self.owned:
             return
-        g = self.geo
+        g, local = self.geo, self.sets[k]["local"]
         self.ctx.tile_extract(image.data_ptr(), g.canvas_h, g.canvas_w, g.cn, image.stride(0),
                               [g.rects[t] for t in self.owned],
-                              [self.local_tiles[t].data_ptr() for t in self.owned],
-                              [self.local_tiles[t].stride(0) for t in self.owned])
+                              [local[t].data_ptr() for t in self.owned],
+                              [local[t].stride(0) for t in self.owned])
 
-    def stage_exchange(self):
+    def stage_exchange(self, k: int = 0):
         """Posts the grouped sends / receives; returns the work handles (empty on one GPU)."""
         if self.world == 1:
             return []
-        return exchange_tile_rows(self.xplan, self.rank, self.local_tiles, self.recv_bufs, self.group)
+        return exchange_tile_rows(self.xplan, self.rank, self.sets[k]["local"], self.sets[k]["recv"], self.group)
 
-    def stage_blend(self, pending=()):
+    def stage_blend(self, pending=(), k: int = 0):
         """Pyramids of the tiles this rank already holds run while the exchange is in flight; the tiles that
         arrive are processed after the wait, then the canvas gather over all of them."""
+        ptrs = self.sets[k]["ptrs"]
         if not pending:
-            self.plan.blend(self._ptrs, self._strides, self.canvas.data_ptr(), self.canvas.stride(0))
+            self.plan.blend(ptrs, self._strides, self.canvas.data_ptr(), self.canvas.stride(0))
             return
-        self.plan.pyramids(self._ptrs, self._strides, self._local_needed, first=True)
+        self.plan.pyramids(ptrs, self._strides, self._local_needed, first=True)
         for w in pending:
             w.wait()
-        self.plan.pyramids(self._ptrs, self._strides, self._remote_needed, first=False)
-        self.plan.gather(self._ptrs, self._strides, self.canvas.data_ptr(), self.canvas.stride(0))
+        self.plan.pyramids(ptrs, self._strides, self._remote_needed, first=False)
+        self.plan.gather(ptrs, self._strides, self.canvas.data_ptr(), self.canvas.stride(0))
 
-    def stage_assess(self, reference):
+    def stage_assess(self, reference, k: int = 0):
         """PSNR (exact integer SSE) and the three SSIM variants over this rank's strip, as partial sums left on
-        the device: one fused fp64 pass (SSE + Gaussian cropped + Gaussian full-frame) and one integer pass
-        (uniform 7x7) -- sr_assess_u8_async."""
+        the device: one fused pass over both images -- sr_assess_u8_async."""
         g = self.geo
         s0, s1 = self.strip
         flags = _native.ASSESS_SSE
@@ -338,25 +360,79 @@ class DevicePipeline:
             if mode in self.ssim_modes:
                 flags |= bit
         self.ctx.assess_u8_async(reference.data_ptr(), reference.stride(0), self.canvas.data_ptr(),
-                                 self.canvas.stride(0), g.canvas_h, g.canvas_w, g.cn, self.results.data_ptr(),
-                                 flags=flags, row_begin=s0, row_end=s1)
+                                 self.canvas.stride(0), g.canvas_h, g.canvas_w, g.cn,
+                                 self.sets[k]["results"].data_ptr(), flags=flags, row_begin=s0, row_end=s1)
 
-    def stage_reduce(self):
-        if self.world > 1:
-            import torch.distributed as dist
-            if dist.get_backend(self.group) == "gloo":          # rehearsal backend: reduce on the host
-                host = self.results.cpu()
-                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
-                self.results.copy_(host)
-            else:
-                dist.all_reduce(self.results, op=dist.ReduceOp.SUM, group=self.group)
+    def stage_reduce(self, k: int = 0, async_op: bool = False):
+        if self.world == 1:
+            return None
+        import torch.distributed as dist
+        res = self.sets[k]["results"]
+        if dist.get_backend(self.group) == "gloo":          # rehearsal backend: reduce on the host
+            host = res.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            res.copy_(host)
+            return None
+        return dist.all_reduce(res, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
     def step(self, image, reference):
+        """One image, start to finish (buffer set 0)."""
         self.stage_tile(image)
         pending = self.stage_exchange()
         self.stage_blend(pending)
         self.stage_assess(reference)
         self.stage_reduce()
+        self._done = 0
+
+    # -- a stream of images: the exchange of image i+1 overlaps the blend / assessment of image i -----------------
+    def pipeline_begin(self, image):
+        """Tile stage + posted exchange of the first image of a stream."""
+        self._cur = 0
+        self.stage_tile(image, 0)
+        self._pending = self.stage_exchange(0)
+
+    def pipeline_step(self, reference, next_image=None):
+        """Finishes the image in flight; when ``next_image`` is given its tile stage and exchange are started as soon
+        as this image's rows have arrived, into the other buffer set, so the transfer runs under the remaining
+        pyramids, the canvas gather and the assessment of this image.  Every image still gets every stage; only the
+        order across images changes.  One exchange batch is in flight at any time."""
+        k = self._cur
+        ptrs, pending = self.sets[k]["ptrs"], self._pending
+        staged = bool(pending)
+        if staged:
+            self.plan.pyramids(ptrs, self._strides, self._local_needed, first=True)
+            for w in pending:
+                w.wait()
+        nk = (k + 1) % len(self.sets)
+        overlap = next_image is not None and nk != k
+        if overlap:                                       # start image i+1 before the rest of image i
+            self.stage_tile(next_image, nk)
+            self._pending = self.stage_exchange(nk)
+        self._finish_blend(k, staged)
+        self.stage_assess(reference, k)
+        for w in self._reduce_work:                       # the previous image's sums (other buffer set)
+            w.wait()
+        w = self.stage_reduce(k, async_op=True)
+        self._reduce_work = [w] if w is not None else []
+        if next_image is not None and not overlap:        # one buffer set (single GPU): plain order
+            self.stage_tile(next_image, nk)
+            self._pending = self.stage_exchange(nk)
+        elif next_image is None:
+            self._pending = None
+        self._done, self._cur = k, nk
+
+    def _finish_blend(self, k, staged):
+        ptrs = self.sets[k]["ptrs"]
+        if staged:
+            self.plan.pyramids(ptrs, self._strides, self._remote_needed, first=False)
+            self.plan.gather(ptrs, self._strides, self.canvas.data_ptr(), self.canvas.stride(0))
+        else:
+            self.plan.blend(ptrs, self._strides, self.canvas.data_ptr(), self.canvas.stride(0))
+
+    def pipeline_finish(self):
+        for w in self._reduce_work:
+            w.wait()
+        self._reduce_work = []
 
     # -- single-process rehearsal of a rank (tests): same buffers, same staged kernels, no communicator ------------
     def rehearse_fill(self, full_tiles: Dict[int, "object"]):
@@ -373,6 +449,7 @@ class DevicePipeline:
         self.plan.pyramids(self._ptrs, self._strides, self._remote_needed, first=False)
         self.plan.gather(self._ptrs, self._strides, self.canvas.data_ptr(), self.canvas.stride(0))
         self.stage_assess(reference)
+        self._done = 0
 
     # -- results ----------------------------------------------------------------------------------
     def metrics(self) -> Dict[str, float]:

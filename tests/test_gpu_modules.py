@@ -257,6 +257,33 @@ def test_full_size_200mp_properties():
     pipe.close()
 
 
+def test_device_pipeline_stream_equals_single_steps(rng):
+    """pipeline_begin / pipeline_step over a stream of different images gives, image by image, the canvas and sums of
+    step() (bench.py times the stream form)."""
+    import torch
+    import device_pipeline as dp
+    geo = dp.grid_geometry(tile_w=300, tile_h=260, rows=2, cols=3, ov_x=70)
+    H, W = geo.canvas_h, geo.canvas_w
+    imgs = [torch.from_numpy(_img(rng, H, W).reshape(H, -1)).cuda() for _ in range(3)]
+    ref = torch.from_numpy(_img(rng, H, W).reshape(H, -1)).cuda()
+    one = dp.DevicePipeline(geo, 0, 1, 0)
+    want = []
+    for im in imgs:
+        one.step(im, ref)
+        torch.cuda.synchronize()
+        want.append((one.canvas.clone(), one.results.clone()))
+    pipe = dp.DevicePipeline(geo, 0, 1, 0)
+    pipe.pipeline_begin(imgs[0])
+    for i in range(3):
+        pipe.pipeline_step(ref, imgs[i + 1] if i + 1 < 3 else None)
+        torch.cuda.synchronize()
+        assert torch.equal(pipe.canvas, want[i][0])
+        assert torch.equal(pipe.results, want[i][1])
+    pipe.pipeline_finish()
+    one.close()
+    pipe.close()
+
+
 def test_device_pipeline_kd_tiling(rng):
     """BASELINE config 5 geometry at test size: non-uniform k-d rectangles (odd origins, widths not a multiple of 4,
     one weight class per tile) through the same pipeline object -- canvas and scores equal the oracle's."""
