@@ -47,4 +47,16 @@ for k in sorted(set(fetch) | set(write)):
     rd, wr = fetch.get(k, 0.0) * 1024.0 * cal, write.get(k, 0.0) * 1024.0
     out["kernels"][k] = {"read": rd, "write": wr, "total": rd + wr}
 json.dump(out, open(f"profiles/{prefix}_traffic.json", "w"), indent=1)
+# the bench line of this collection was printed before this summary existed: point its roofline at these counters
+roof = bench.get("roofline") or {}
+if roof.get("kernel"):
+    sys.path.insert(0, ".")
+    import bench as bench_mod
+    names = bench_mod.ROCPROF_NAMES.get(roof["kernel"], [])
+    names = names if isinstance(names, list) else [names]
+    vals = [out["kernels"][n]["total"] for n in names if n in out["kernels"]]
+    if vals:
+        lps = bench["kernels"][roof["kernel"]]["launches_per_step"]
+        roof["traffic"], roof["traffic_source"] = sum(vals) / max(lps, 1), f"{prefix}_traffic.json"
+        json.dump(bench, open(f"profiles/{prefix}_bench.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
