@@ -66,9 +66,9 @@ def algorithmic_bytes(geo) -> dict:
 
 
 # bench kernel family -> rocprofv3 kernel name (profiles/*_traffic.json)
-ROCPROF_NAMES = {"tile_extract": "k_tile_extract", "down_l0": ["k_down_march<0, 3>", "k_down_cols<0>"],
-                 "down_l1p": ["k_down_march<2, 3>", "k_down_cols<2>"],
-                 "up_level": "k_up_level_blk<3>", "final_gather": ["k_final_fast<0, true, 3>", "k_final_edge<0, true, 3>"],
+ROCPROF_NAMES = {"tile_extract": "k_tile_extract", "down_l0": "k_down_march<0, 3>",
+                 "down_l1p": "k_down_march<2, 3>",
+                 "up_level": "k_up_level_blk<3>", "final_gather": "k_final_fast<0, true, 3>",
                  "assess_all": "k_assess_march<3>"}
 
 

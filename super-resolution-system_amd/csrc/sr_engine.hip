@@ -42,8 +42,18 @@ struct ProfPair {
     hipEvent_t a, b;
 };
 
+// A small device table with a host shadow of what was last uploaded into it: per-step descriptor tables (tile
+// pointers, strides, rectangles) rarely change between calls, and a host->device copy between two kernels costs a
+// stream bubble of several microseconds -- identical content is not uploaded again.
+struct CachedTable {
+    void *d = nullptr;
+    size_t cap = 0;
+    std::vector<char> shadow;
+};
+
 struct sr_ctx {
     int device = 0;
+    int num_cu = 256;               // compute units of the device (launch-shape heuristics)
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::recursive_mutex mu;
@@ -56,6 +66,7 @@ struct sr_ctx {
     size_t scratch_bytes = 0;
     // host copies of small tables handed to hipMemcpyAsync; released at the next stream sync
     std::vector<std::vector<char>> pending_host;
+    CachedTable extract_tab;                            // tile-extract descriptors
 };
 
 // Enqueue a small host->device table upload whose source stays alive until the next sync.
@@ -63,6 +74,35 @@ static hipError_t upload_small(sr_ctx *c, void *d_dst, const void *h_src, size_t
 {
     c->pending_host.emplace_back((const char *)h_src, (const char *)h_src + bytes);
     return hipMemcpyAsync(d_dst, c->pending_host.back().data(), bytes, hipMemcpyHostToDevice, c->stream);
+}
+
+static hipError_t stream_sync(sr_ctx *c);
+
+// Upload into a fixed destination unless `shadow` shows the same bytes are already there.
+static hipError_t upload_if_changed(sr_ctx *c, void *d_dst, const void *h_src, size_t bytes, std::vector<char> &shadow)
+{
+    if (shadow.size() == bytes && bytes > 0 && memcmp(shadow.data(), h_src, bytes) == 0) return hipSuccess;
+    shadow.assign((const char *)h_src, (const char *)h_src + bytes);
+    return upload_small(c, d_dst, h_src, bytes);
+}
+
+// Same with a table that owns (and grows) its device buffer.
+static hipError_t upload_cached(sr_ctx *c, CachedTable &t, const void *h_src, size_t bytes)
+{
+    if (bytes > t.cap) {
+        if (t.d) {
+            hipError_t e = stream_sync(c);
+            if (e != hipSuccess) return e;
+            (void)hipFree(t.d);
+            t.d = nullptr;
+        }
+        const size_t nb = std::max<size_t>((bytes + 4095) / 4096 * 4096, 4096);
+        hipError_t e = hipMalloc(&t.d, nb);
+        if (e != hipSuccess) { t.cap = 0; return e; }
+        t.cap = nb;
+        t.shadow.clear();
+    }
+    return upload_if_changed(c, t.d, h_src, bytes, t.shadow);
 }
 
 static hipError_t stream_sync(sr_ctx *c)
@@ -350,7 +390,8 @@ __global__ __launch_bounds__(256) void k_down(const TileDev *__restrict__ tiles,
 // 2 x0 - 2 .. 2 x0 + 8) and walks down seg_rows output rows: every input row is loaded once and its horizontal pass
 // evaluated once; the five row-pass results an output row needs (rows 2y-2 .. 2y+2) live in registers.  Row indices
 // go through REFLECT_101, so the top / bottom tile borders need no separate path.  Only "interior" column groups
-// (whole window inside the row: cg = 1 .. ncg) run here; the few border columns of a level go to k_down_cols.
+// (whole window inside the row: cg = 1 .. ncg) take the march; the few border columns of a level are done by the
+// trailing blocks of the same launch.
 // Lanes are laid over (segment, column group) cells flattened per tile, so waves are full except the last one.
 // seg_rows (output rows per segment, chosen per launch): longer segments amortise the 3-row prologue, shorter ones
 // keep enough cells in flight on the small levels.
@@ -411,13 +452,30 @@ __device__ __forceinline__ void down_row_f32(const float (&s)[11], float (&h)[4]
 
 template <int SRC, int CN>
 __global__ __launch_bounds__(256) void k_down_march(const TileDev *__restrict__ tiles, const TileSrc *__restrict__ srcs,
-                                                    int lvl, int seg_rows, float *__restrict__ arena)
+                                                    int lvl, int seg_rows, int march_blocks, float *__restrict__ arena,
+                                                    const float *__restrict__ luts)
 {
     const TileDev &T = tiles[blockIdx.z];
     if (lvl + 1 >= T.nl) return;
     const int ws = T.W[lvl], hs = T.H[lvl], wo = T.W[lvl + 1];
     const int ya = T.g0[lvl + 1], yb = T.g1[lvl + 1];
     const int ncg = down_ncg(ws, wo);
+    if ((int)blockIdx.x >= march_blocks) {
+        // The border columns the march leaves out: outputs 0 .. 3 and 4 (ncg + 1) .. wo - 1 (at most 12 columns;
+        // every column when the level has no interior column group), one pixel per thread with the full border
+        // rule -- the trailing blocks of the same launch, 16 columns x 16 rows each.
+        const int tid = threadIdx.y * 64 + threadIdx.x;
+        const int e = tid & 15;
+        const int x = (ncg <= 0 || e < 4) ? e : 4 * (ncg + 1) + (e - 4);
+        const int y = ya + ((int)blockIdx.x - march_blocks) * 16 + (tid >> 4);
+        if (x >= wo || y >= yb) return;
+        TileSrc S;
+        S.p = nullptr;
+        S.stride = 0;
+        if (SRC == SRC_U8) S = srcs[blockIdx.z];
+        down_pixel<SRC>(T, S, lvl, CN, x, y, arena, luts);
+        return;
+    }
     if (ncg <= 0 || yb <= ya) return;
     const int nseg = (yb - ya + seg_rows - 1) / seg_rows;
     const int cell = blockIdx.x * 256 + threadIdx.y * 64 + threadIdx.x;
@@ -499,28 +557,6 @@ __global__ __launch_bounds__(256) void k_down_march(const TileDev *__restrict__ 
             }
         }
     }
-}
-
-// The border columns of a level that k_down_march leaves out: outputs 0 .. 3 and 4 (ncg + 1) .. wo - 1 (at most 12
-// columns; every column when the level has no interior column group), one pixel per thread with the full border rule.
-template <int SRC>
-__global__ __launch_bounds__(256) void k_down_cols(const TileDev *__restrict__ tiles, const TileSrc *__restrict__ srcs,
-                                                   int lvl, int cn, float *__restrict__ arena,
-                                                   const float *__restrict__ luts)
-{
-    const TileDev &T = tiles[blockIdx.z];
-    if (lvl + 1 >= T.nl) return;
-    const int wo = T.W[lvl + 1];
-    const int ncg = down_ncg(T.W[lvl], wo);
-    const int e = threadIdx.x;
-    const int x = (ncg <= 0 || e < 4) ? e : 4 * (ncg + 1) + (e - 4);
-    const int y = T.g0[lvl + 1] + blockIdx.y * 16 + threadIdx.y;
-    if (x >= wo || y >= T.g1[lvl + 1]) return;
-    TileSrc S;
-    S.p = nullptr;
-    S.stride = 0;
-    if (SRC == SRC_U8 || SRC == SRC_F32) S = srcs[blockIdx.z];
-    down_pixel<SRC>(T, S, lvl, cn, x, y, arena, luts);
 }
 
 // R_i for one level of every tile:  top level: G*W;  else up(R_{i+1}) + (G_i - up(G_{i+1})) * W_i
@@ -725,7 +761,7 @@ __device__ __forceinline__ void up_block_interior(const float *__restrict__ plan
 
 // Is the thread's 4 x 2 rectangle (tile-local origin lx0, ly0; nx x ny of it on the canvas strip) an
 // "interior" visit of tile D: all eight pixels inside the tile and every level-1 tap away from the borders?
-// Interior visits run in k_final_fast, everything else in k_final_edge; both kernels evaluate this same test.
+// Interior visits run in the regular blocks of k_final_fast, everything else in its edge blocks; both evaluate this same test.
 template <bool LAP>
 __device__ __forceinline__ bool visit_is_interior(const FinalDesc &D, int lx0, int ly0, int nx, int ny)
 {
@@ -1096,58 +1132,19 @@ __device__ __forceinline__ void store_pixels(float (&acc)[2][4][CN], const float
 // id, list entries and the 80-byte descriptors are wave-uniform, so they travel through the scalar cache into
 // SGPRs: no LDS staging and no barrier before the first vector load.
 
-// Final gather, pass 1: threads all of whose tile visits are interior.  Threads with any border visit leave
-// their pixels to k_final_edge.
+// Final gather, border part: the cells the interior part leaves out (a border visit).  Runs over the blocks of the
+// edge work list built on the host when the plan is made: 256 x 8 pixel blocks along horizontal tile edges (shape 0),
+// 16 x 128 pixel blocks along vertical ones (shape 1).  These are the leading blocks of k_final_fast's launch (the
+// slow, divergent ones are scheduled first, the kernel's tail is made of regular blocks).
 template <int DT, bool LAP, int CN>
-__global__ __launch_bounds__(256, 3) void k_final_fast(const FinalDesc *__restrict__ descs,
-                                                       const int *__restrict__ cand_off, const int *__restrict__ cand_idx,
-                                                       const float *__restrict__ arena, const float *__restrict__ luts,
-                                                       unsigned char *__restrict__ canvas, long long cstride,
-                                                       float *__restrict__ canvas_f32, int cw, int row_begin, int row_end)
+__device__ __forceinline__ void final_edge_block(const FinalDesc *__restrict__ descs, const int4 *__restrict__ edge_blocks,
+                                                 int ebi, const int *__restrict__ cand_idx,
+                                                 const float *__restrict__ arena, const float *__restrict__ luts,
+                                                 unsigned char *__restrict__ canvas, long long cstride,
+                                                 float *__restrict__ canvas_f32, int cw, int row_begin, int row_end)
 {
-    const int blk = blockIdx.y * gridDim.x + blockIdx.x;
-    const int c_begin = cand_off[blk], c_end = cand_off[blk + 1];
-    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int y0 = row_begin + (blockIdx.y * 4 + threadIdx.y) * 2;
-    if (x0 >= cw || y0 >= row_end) return;
-    const int nx = min(4, cw - x0), ny = min(2, row_end - y0);
-    float acc[2][4][CN], wacc[2][4];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            wacc[j][k] = 0.f;
-#pragma unroll
-            for (int c = 0; c < CN; ++c) acc[j][k][c] = 0.f;
-        }
-    for (int i = c_begin; i < c_end; ++i) {
-        const FinalDesc &D = descs[cand_idx[i]];
-        const int lx0 = x0 - D.x, ly0 = y0 - D.y;
-        if (lx0 + nx <= 0 || ly0 + ny <= 0 || lx0 >= D.w || ly0 >= D.h) continue;
-        // one border visit sends the whole thread to the edge pass (which recomputes every visit)
-        if (!visit_is_interior<LAP>(D, lx0, ly0, nx, ny)) return;
-        const bool xo = (D.x & 1) != 0;                      // x0 is a multiple of 4
-        const bool yo = ((row_begin - D.y) & 1) != 0;        // y0 - row_begin is a multiple of 2
-        if (!xo && !yo) gather_tile_fast<DT, LAP, CN, false, false>(D, arena, luts, lx0, ly0, acc, wacc);
-        else if (xo && !yo) gather_tile_fast<DT, LAP, CN, true, false>(D, arena, luts, lx0, ly0, acc, wacc);
-        else if (!xo && yo) gather_tile_fast<DT, LAP, CN, false, true>(D, arena, luts, lx0, ly0, acc, wacc);
-        else gather_tile_fast<DT, LAP, CN, true, true>(D, arena, luts, lx0, ly0, acc, wacc);
-    }
-    store_pixels<CN>(acc, wacc, canvas, cstride, canvas_f32, cw, x0, y0, nx, ny);
-}
-
-// Final gather, pass 2: the threads pass 1 left out (a border visit).  Launched only over the blocks of the edge
-// work list built on the host when the plan is made: 256 x 8 pixel blocks along horizontal tile edges (shape 0),
-// 16 x 128 pixel blocks along vertical ones (shape 1).
-template <int DT, bool LAP, int CN>
-__global__ __launch_bounds__(256) void k_final_edge(const FinalDesc *__restrict__ descs,
-                                                    const int4 *__restrict__ edge_blocks, const int *__restrict__ cand_idx,
-                                                    const float *__restrict__ arena, const float *__restrict__ luts,
-                                                    unsigned char *__restrict__ canvas, long long cstride,
-                                                    float *__restrict__ canvas_f32, int cw, int row_begin, int row_end)
-{
-    const int4 eb = edge_blocks[blockIdx.x];
-    const int c_begin = eb.w, c_end = edge_blocks[blockIdx.x + 1].w;
+    const int4 eb = edge_blocks[ebi];
+    const int c_begin = eb.w, c_end = edge_blocks[ebi + 1].w;
     const int tid = threadIdx.y * 64 + threadIdx.x;
     const int x0 = eb.x + (eb.z ? (tid & 3) : (tid & 63)) * 4;
     const int y0 = eb.y + (eb.z ? (tid >> 2) : (tid >> 6)) * 2;
@@ -1187,6 +1184,57 @@ __global__ __launch_bounds__(256) void k_final_edge(const FinalDesc *__restrict_
         else if (xo && !yo) gather_tile_generic<DT, LAP, CN, true, false>(D, arena, luts, lx0, ly0, valid, acc, wacc);
         else if (!xo && yo) gather_tile_generic<DT, LAP, CN, false, true>(D, arena, luts, lx0, ly0, valid, acc, wacc);
         else gather_tile_generic<DT, LAP, CN, true, true>(D, arena, luts, lx0, ly0, valid, acc, wacc);
+    }
+    store_pixels<CN>(acc, wacc, canvas, cstride, canvas_f32, cw, x0, y0, nx, ny);
+}
+
+// Final gather.  Blocks with blockIdx.y < edge_rows work through the edge list (above); the others are the regular
+// 256 x 8 pixel blocks: threads all of whose tile visits are interior compute here, threads with any border visit
+// leave their pixels to the edge blocks.
+template <int DT, bool LAP, int CN>
+__global__ __launch_bounds__(256, 3) void k_final_fast(const FinalDesc *__restrict__ descs,
+                                                       const int *__restrict__ cand_off, const int *__restrict__ cand_idx,
+                                                       const int4 *__restrict__ edge_blocks, const int *__restrict__ edge_cand,
+                                                       int n_edge, int edge_rows,
+                                                       const float *__restrict__ arena, const float *__restrict__ luts,
+                                                       unsigned char *__restrict__ canvas, long long cstride,
+                                                       float *__restrict__ canvas_f32, int cw, int row_begin, int row_end)
+{
+    if ((int)blockIdx.y < edge_rows) {
+        const int ebi = blockIdx.y * gridDim.x + blockIdx.x;
+        if (ebi < n_edge)
+            final_edge_block<DT, LAP, CN>(descs, edge_blocks, ebi, edge_cand, arena, luts, canvas, cstride, canvas_f32, cw,
+                                          row_begin, row_end);
+        return;
+    }
+    const int by = blockIdx.y - edge_rows;
+    const int blk = by * gridDim.x + blockIdx.x;
+    const int c_begin = cand_off[blk], c_end = cand_off[blk + 1];
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y0 = row_begin + (by * 4 + threadIdx.y) * 2;
+    if (x0 >= cw || y0 >= row_end) return;
+    const int nx = min(4, cw - x0), ny = min(2, row_end - y0);
+    float acc[2][4][CN], wacc[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            wacc[j][k] = 0.f;
+#pragma unroll
+            for (int c = 0; c < CN; ++c) acc[j][k][c] = 0.f;
+        }
+    for (int i = c_begin; i < c_end; ++i) {
+        const FinalDesc &D = descs[cand_idx[i]];
+        const int lx0 = x0 - D.x, ly0 = y0 - D.y;
+        if (lx0 + nx <= 0 || ly0 + ny <= 0 || lx0 >= D.w || ly0 >= D.h) continue;
+        // one border visit sends the whole thread to the edge pass (which recomputes every visit)
+        if (!visit_is_interior<LAP>(D, lx0, ly0, nx, ny)) return;
+        const bool xo = (D.x & 1) != 0;                      // x0 is a multiple of 4
+        const bool yo = ((row_begin - D.y) & 1) != 0;        // y0 - row_begin is a multiple of 2
+        if (!xo && !yo) gather_tile_fast<DT, LAP, CN, false, false>(D, arena, luts, lx0, ly0, acc, wacc);
+        else if (xo && !yo) gather_tile_fast<DT, LAP, CN, true, false>(D, arena, luts, lx0, ly0, acc, wacc);
+        else if (!xo && yo) gather_tile_fast<DT, LAP, CN, false, true>(D, arena, luts, lx0, ly0, acc, wacc);
+        else gather_tile_fast<DT, LAP, CN, true, true>(D, arena, luts, lx0, ly0, acc, wacc);
     }
     store_pixels<CN>(acc, wacc, canvas, cstride, canvas_f32, cw, x0, y0, nx, ny);
 }
@@ -1530,6 +1578,7 @@ enum { ASSESS_SSE = 1, ASSESS_UNIFORM = 2, ASSESS_GAUSS = 4, ASSESS_SIMPLE = 8, 
 
 struct AssessParams {
     int h, w, shift, ry0, ry1, flags, same_c;
+    int nch, ty;       // chunks of 11 rows a block marches, and the rows it produces (11 nch - 10)
     double c1a, c2a;   // constants for data_range (uniform / gauss)
     double c1b, c2b;   // constants for 255 (simple)
     double k[6];       // k[0] centre tap, k[j] the +-j taps
@@ -1582,7 +1631,7 @@ __device__ __forceinline__ double ssim_value(double ux, double uy, double spq, d
 
 // ---------------------------------------------------------------------------------------------
 // k_assess_march: all four metrics in ONE pass, column-marching.  A block is 256 columns wide (768 B of RGB per
-// row: whole cache lines, ~4 % column halo) and walks down AM_TY + 10 rows in chunks of 11.  Per chunk the block
+// row: whole cache lines, ~4 % column halo) and walks down P.ty + 10 rows in chunks of 11.  Per chunk the block
 // converts 11 rows of both images to gray once per pixel and leaves, per pixel, three dwords in LDS: x | y << 16,
 // x*y and x^2 + y^2 (so no thread ever recomputes a neighbour's products, and one packed add pair-sums x and y
 // together).  Then each thread owns one column: the row pass of its column (integer pair sums, 6 fp64 products per
@@ -1595,9 +1644,8 @@ __device__ __forceinline__ double ssim_value(double ux, double uy, double spq, d
 #define AM_R 5
 #define AM_GP 272                       /* row pitch in pixels: 68 groups of 4 */
 #define AM_CH 11                        /* rows per chunk == FIFO depth */
-#define AM_NCH 12                       /* chunks per block */
-#define AM_ROWS (AM_CH * AM_NCH)        /* 132 rows marched */
-#define AM_TY (AM_ROWS - 2 * AM_R)      /* 122 output rows per block; LDS 36 KB + 14 KB ring -> 3 blocks per CU */
+#define AM_NCH_MAX 12                   /* chunks per block: P.nch <= 12, chosen per launch (rows / tail effect) */
+/* a block marches 11 * nch rows and produces P.ty = 11 * nch - 10 of them; LDS 36 KB + 14 KB ring -> 3 blocks per CU */
 
 // gray conversion + per-pixel products of 4-pixel groups of chunk `ch` into LDS; returns this thread's share of the
 // squared differences of the block's own pixels
@@ -1665,7 +1713,7 @@ __device__ __forceinline__ unsigned long long assess_load_chunk(const unsigned c
         *(u4_t *)&XY[ly][lx] = vxy;
         *(u4_t *)&QQ[ly][lx] = vq;
         *(u4_t *)&PP[ly][lx] = vp;
-        if (want_sse && lr >= AM_R && lr < AM_R + AM_TY && gy < P.ry1 && gy < P.h) {
+        if (want_sse && lr >= AM_R && lr < AM_R + P.ty && gy < P.ry1 && gy < P.h) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (lx + k >= AM_R && lx + k < AM_R + AM_TX && gx + k < P.w) sse += sq[k];
@@ -1685,8 +1733,8 @@ __global__ __launch_bounds__(256) void k_assess_march(const unsigned char *__res
     __shared__ int U[7][2][AM_TX];      // per-row 7-tap sums, 61 bits packed: {sx:11, sy:11, sq lo:10}, {sp:21, sq hi:9}
     __shared__ double red[4][4];
     const int c = threadIdx.x;
-    const int bx0 = blockIdx.x * AM_TX, by0 = P.ry0 + blockIdx.y * AM_TY;
-    const int rows_needed = min(AM_TY, P.ry1 - by0) + 2 * AM_R;          // block-uniform
+    const int bx0 = blockIdx.x * AM_TX, by0 = P.ry0 + blockIdx.y * P.ty;
+    const int rows_needed = min(P.ty, P.ry1 - by0) + 2 * AM_R;          // block-uniform
     const int mx = bx0 + c;
     const bool col_ok = mx < P.w;
     const bool do_u = (P.flags & ASSESS_UNIFORM) != 0, do_g = (P.flags & (ASSESS_GAUSS | ASSESS_SIMPLE)) != 0;
@@ -1702,7 +1750,7 @@ __global__ __launch_bounds__(256) void k_assess_march(const unsigned char *__res
     const double inv49 = 1.0 / 49.0, cn49 = 49.0 / 48.0;
     int slot = 0;                                                       // row index mod 7
 #pragma unroll 1
-    for (int ch = 0; ch < AM_NCH; ++ch) {
+    for (int ch = 0; ch < P.nch; ++ch) {
         if (ch * AM_CH >= rows_needed) break;
         __syncthreads();                                                // the previous chunk has been read
         sse += assess_load_chunk<CN>(a, sa, b, sb, P, bx0, by0, ch, rows_needed, XY, QQ, PP);
@@ -1745,7 +1793,7 @@ __global__ __launch_bounds__(256) void k_assess_march(const unsigned char *__res
                     U[slot][0][c] = (int)((uxy & 0x7FFu) | ((uxy >> 16) << 11) | ((uq & 0x3FFu) << 22));
                     U[slot][1][c] = (int)(up | ((uq >> 10) << 21));
                     const int orow = r - 8, my = by0 + orow;             // window rows r-6 .. r, centre r-3
-                    if (orow >= 0 && orow < AM_TY && my < P.ry1 && my >= 3 && my < P.h - 3 && u_col) {
+                    if (orow >= 0 && orow < P.ty && my < P.ry1 && my >= 3 && my < P.h - 3 && u_col) {
                         const double mux = (double)(t_xy & 0xFFFF) * inv49, muy = (double)((unsigned)t_xy >> 16) * inv49;
                         const double sxxyy = (double)t_p * inv49;                    // (sum xx + sum yy) / 49, exact integers
                         const double sxy = (double)t_q * inv49;                      // sum xy / 49
@@ -1757,7 +1805,7 @@ __global__ __launch_bounds__(256) void k_assess_march(const unsigned char *__res
                 }
                 if (do_g && r >= 2 * AM_R) {
                     const int orow = r - 2 * AM_R, my = by0 + orow;      // rows r-10 .. r are in the FIFO, centre r-5
-                    if (orow < AM_TY && my < P.ry1 && my < P.h && col_ok) {
+                    if (orow < P.ty && my < P.ry1 && my < P.h && col_ok) {
                         double u[4];
 #pragma unroll
                         for (int m = 0; m < 4; ++m) {
@@ -2002,6 +2050,9 @@ struct sr_blend_plan {
     int n_edge_blocks = 0;
     int *d_cand_off = nullptr, *d_cand_idx = nullptr;   // per 256 x 8 block: candidate tiles (CSR, list order)
     bool weights_ready = false;                         // weight pyramids of the classes are in the arena
+    std::vector<char> sh_srcs, sh_fdesc;                // host shadows of d_srcs / d_fdesc (upload_if_changed)
+    CachedTable subset_tabs[4];                         // compacted {TileDev, TileSrc} tables of recent tile subsets
+    int subset_next = 0;
     float *d_luts = nullptr;
     // launch extents per level
     int max_w[SR_MAX_LEVELS] = {0}, max_grows[SR_MAX_LEVELS] = {0}, max_rrows[SR_MAX_LEVELS] = {0};
@@ -2040,6 +2091,10 @@ static int ctx_create_impl(int device_id, void *stream, bool adopt, sr_ctx **out
     HIPCHK(hipSetDevice(device_id));
     sr_ctx *c = new sr_ctx();
     c->device = device_id;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) c->num_cu = cus;
+    }
     if (adopt) {
         c->stream = (hipStream_t)stream;
         c->own_stream = false;
@@ -2087,6 +2142,7 @@ int sr_ctx_destroy(sr_ctx *ctx)
         }
         for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
         if (ctx->scratch) (void)hipFree(ctx->scratch);
+        if (ctx->extract_tab.d) (void)hipFree(ctx->extract_tab.d);
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;
@@ -2216,10 +2272,8 @@ static int extract_impl(sr_ctx *ctx, const uint8_t *d_img, int img_h, int img_w,
         mw = std::max(mw, d.out_w);
         mh = std::max(mh, d.out_h);
     }
-    void *scr = nullptr;
-    int rc = ctx_scratch(ctx, sizeof(ExtractDesc) * n, &scr);
-    if (rc) return rc;
-    HIPCHK(upload_small(ctx, scr, descs.data(), sizeof(ExtractDesc) * n));
+    HIPCHK(upload_cached(ctx, ctx->extract_tab, descs.data(), sizeof(ExtractDesc) * n));
+    const void *scr = ctx->extract_tab.d;
     {
         ProfScope ps(ctx, name);
         const long long chunks = ((long long)mw * cn + 15) / 16;
@@ -2352,6 +2406,8 @@ int sr_blend_plan_destroy(sr_blend_plan *plan)
         if (plan->d_edge_blocks) (void)hipFree(plan->d_edge_blocks);
         if (plan->d_edge_cand) (void)hipFree(plan->d_edge_cand);
         if (plan->d_cand_off) (void)hipFree(plan->d_cand_off);
+        for (auto &t : plan->subset_tabs)
+            if (t.d) (void)hipFree(t.d);
         if (plan->d_cand_idx) (void)hipFree(plan->d_cand_idx);
         if (plan->d_luts) (void)hipFree(plan->d_luts);
     }
@@ -2692,18 +2748,26 @@ static int blend_pyramids(sr_blend_plan *P, int dtype, void *const *h_d_tiles, c
         }
     }
     if (all) {
-        HIPCHK(upload_small(ctx, P->d_srcs, sub_s.data(), sizeof(TileSrc) * n_idx));
+        HIPCHK(upload_if_changed(ctx, P->d_srcs, sub_s.data(), sizeof(TileSrc) * n_idx, P->sh_srcs));
     } else {
         sub_t.resize(n_idx);
         for (int k = 0; k < n_idx; ++k) sub_t[k] = P->tiles[idx[k]];
         auto al = [](size_t v) { return (v + 255) / 256 * 256; };
-        void *scr = nullptr;
-        int rc = ctx_scratch(ctx, al(sizeof(TileDev) * n_idx) + al(sizeof(TileSrc) * n_idx), &scr);
-        if (rc) return rc;
-        HIPCHK(upload_small(ctx, scr, sub_t.data(), sizeof(TileDev) * n_idx));
-        HIPCHK(upload_small(ctx, (char *)scr + al(sizeof(TileDev) * n_idx), sub_s.data(), sizeof(TileSrc) * n_idx));
-        d_tiles = (const TileDev *)scr;
-        d_srcs = (const TileSrc *)((char *)scr + al(sizeof(TileDev) * n_idx));
+        const size_t o_src = al(sizeof(TileDev) * n_idx), total = o_src + al(sizeof(TileSrc) * n_idx);
+        std::vector<char> packed(total, 0);
+        memcpy(packed.data(), sub_t.data(), sizeof(TileDev) * n_idx);
+        memcpy(packed.data() + o_src, sub_s.data(), sizeof(TileSrc) * n_idx);
+        // a subset seen recently (the held / arriving halves of a staged blend alternate) keeps its device table
+        CachedTable *slot = nullptr;
+        for (auto &t : P->subset_tabs)
+            if (t.shadow.size() == total && memcmp(t.shadow.data(), packed.data(), total) == 0) slot = &t;
+        if (!slot) {
+            slot = &P->subset_tabs[P->subset_next];
+            P->subset_next = (P->subset_next + 1) % 4;
+        }
+        HIPCHK(upload_cached(ctx, *slot, packed.data(), total));
+        d_tiles = (const TileDev *)slot->d;
+        d_srcs = (const TileSrc *)((const char *)slot->d + o_src);
     }
     // Gaussian chain
     for (int i = 0; i + 1 < max_nl; ++i) {
@@ -2726,19 +2790,17 @@ static int blend_pyramids(sr_blend_plan *P, int dtype, void *const *h_d_tiles, c
                 }
                 if (total >= 512 * 1024) break;
             }
-            if (max_cells > 0) {
-                dim3 grid((max_cells + 255) / 256, 1, n_idx);
+            {
+                const int march_blocks = (max_cells + 255) / 256, cols_blocks = (max_g[i + 1] + 15) / 16;
+                dim3 grid(march_blocks + cols_blocks, 1, n_idx);
                 if (i == 0) {
-                    if (P->cn == 3) hipLaunchKernelGGL((k_down_march<SRC_U8, 3>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, seg_rows, P->d_arena);
-                    else hipLaunchKernelGGL((k_down_march<SRC_U8, 1>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, seg_rows, P->d_arena);
+                    if (P->cn == 3) hipLaunchKernelGGL((k_down_march<SRC_U8, 3>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, seg_rows, march_blocks, P->d_arena, P->d_luts);
+                    else hipLaunchKernelGGL((k_down_march<SRC_U8, 1>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, seg_rows, march_blocks, P->d_arena, P->d_luts);
                 } else {
-                    if (P->cn == 3) hipLaunchKernelGGL((k_down_march<SRC_PLANAR, 3>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, seg_rows, P->d_arena);
-                    else hipLaunchKernelGGL((k_down_march<SRC_PLANAR, 1>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, seg_rows, P->d_arena);
+                    if (P->cn == 3) hipLaunchKernelGGL((k_down_march<SRC_PLANAR, 3>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, seg_rows, march_blocks, P->d_arena, P->d_luts);
+                    else hipLaunchKernelGGL((k_down_march<SRC_PLANAR, 1>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, seg_rows, march_blocks, P->d_arena, P->d_luts);
                 }
             }
-            dim3 cgrid(1, (max_g[i + 1] + 15) / 16, n_idx), cblock(16, 16);
-            if (i == 0) hipLaunchKernelGGL(k_down_cols<SRC_U8>, cgrid, cblock, 0, ctx->stream, d_tiles, d_srcs, i, P->cn, P->d_arena, P->d_luts);
-            else hipLaunchKernelGGL(k_down_cols<SRC_PLANAR>, cgrid, cblock, 0, ctx->stream, d_tiles, d_srcs, i, P->cn, P->d_arena, P->d_luts);
             continue;
         }
         dim3 grid((max_w[i + 1] + 63) / 64, (max_g[i + 1] + 3) / 4, n_idx);
@@ -2783,23 +2845,19 @@ static int blend_gather(sr_blend_plan *P, bool lap, int dtype, void *const *h_d_
         P->fdesc[t].src = h_d_tiles[t];
         P->fdesc[t].stride = h_strides[t];
     }
-    HIPCHK(upload_small(ctx, P->d_srcs, srcs.data(), sizeof(TileSrc) * P->n));
-    HIPCHK(upload_small(ctx, P->d_fdesc, P->fdesc.data(), sizeof(FinalDesc) * P->n));
+    HIPCHK(upload_if_changed(ctx, P->d_srcs, srcs.data(), sizeof(TileSrc) * P->n, P->sh_srcs));
+    HIPCHK(upload_if_changed(ctx, P->d_fdesc, P->fdesc.data(), sizeof(FinalDesc) * P->n, P->sh_fdesc));
     dim3 block(64, 4);
     {
         ProfScope ps(ctx, lap ? "final_gather" : "weighted_gather");
         if (P->cn == 3 || P->cn == 1) {
-            dim3 grid((P->canvas_w + 255) / 256, (rows + 7) / 8);
+            const int nbx = (P->canvas_w + 255) / 256, edge_rows = (P->n_edge_blocks + nbx - 1) / nbx;
+            dim3 grid(nbx, edge_rows + (rows + 7) / 8);
 #define LAUNCH_BLK(DT, LAPV, CNV)                                                                               \
-    do {                                                                                                        \
-        hipLaunchKernelGGL((k_final_fast<DT, LAPV, CNV>), grid, block, 0, ctx->stream, P->d_fdesc,                \
-                           P->d_cand_off, P->d_cand_idx, P->d_arena, P->d_luts, d_canvas,                        \
-                           (long long)canvas_stride, d_canvas_f32, P->canvas_w, P->row_begin, P->row_end);       \
-        if (P->n_edge_blocks > 0)                                                                               \
-            hipLaunchKernelGGL((k_final_edge<DT, LAPV, CNV>), dim3(P->n_edge_blocks), block, 0, ctx->stream,       \
-                               P->d_fdesc, P->d_edge_blocks, P->d_edge_cand, P->d_arena, P->d_luts, d_canvas,      \
-                               (long long)canvas_stride, d_canvas_f32, P->canvas_w, P->row_begin, P->row_end);   \
-    } while (0)
+    hipLaunchKernelGGL((k_final_fast<DT, LAPV, CNV>), grid, block, 0, ctx->stream, P->d_fdesc, P->d_cand_off,     \
+                       P->d_cand_idx, P->d_edge_blocks, P->d_edge_cand, P->n_edge_blocks, edge_rows, P->d_arena, \
+                       P->d_luts, d_canvas, (long long)canvas_stride, d_canvas_f32, P->canvas_w, P->row_begin,   \
+                       P->row_end)
             if (P->cn == 3) {
                 if (lap) { if (dtype == SR_U8) LAUNCH_BLK(SRC_U8, true, 3); else LAUNCH_BLK(SRC_F32, true, 3); }
                 else     { if (dtype == SR_U8) LAUNCH_BLK(SRC_U8, false, 3); else LAUNCH_BLK(SRC_F32, false, 3); }
@@ -3142,7 +3200,7 @@ int sr_weighted_blend_custom(sr_blend_plan *plan, int dtype, void *const *h_d_ti
     void *scr = nullptr;
     rc = ctx_scratch(c, sizeof(CustomW) * P->n + 256, &scr);
     if (rc) return rc;
-    HIPCHK(upload_small(c, P->d_srcs, srcs.data(), sizeof(TileSrc) * P->n));
+    HIPCHK(upload_if_changed(c, P->d_srcs, srcs.data(), sizeof(TileSrc) * P->n, P->sh_srcs));
     HIPCHK(upload_small(c, scr, wts.data(), sizeof(CustomW) * P->n));
     {
         ProfScope ps(c, "weighted_custom");
@@ -3170,6 +3228,35 @@ int sr_sse_u8(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uint8_t *
 
 // ---- fused assessment ---------------------------------------------------------------------------------------
 }  // extern "C"
+
+// Final reduction of the assessment: ONE block sums the per-block partials part[i * 4 + comp] (fixed order: a
+// strided serial sum per thread, then a fixed tree -- deterministic) and writes the four sums.
+__global__ __launch_bounds__(256) void k_assess_finish(const double *__restrict__ part, long long n, int flags,
+                                                       sr_assess_sums *__restrict__ out)
+{
+    __shared__ double sh[4][256];
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (long long i = threadIdx.x; i < n; i += 256) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s[c] += part[i * 4 + c];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sh[c][threadIdx.x] = s[c];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sh[c][threadIdx.x] += sh[c][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out->ssim_gauss = (flags & ASSESS_GAUSS) ? sh[0][0] : 0.0;
+        out->ssim_simple = (flags & ASSESS_SIMPLE) ? sh[1][0] : 0.0;
+        out->sse = (flags & ASSESS_SSE) ? sh[2][0] : 0.0;
+        out->ssim_uniform = (flags & ASSESS_UNIFORM) ? sh[3][0] : 0.0;
+    }
+}
 
 __global__ void k_assess_store(const double *__restrict__ g, const double *__restrict__ u, int flags,
                                sr_assess_sums *__restrict__ out)
@@ -3245,23 +3332,30 @@ int sr_assess_u8_async(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const 
     const int rows = row_end - row_begin;
     const double *res = nullptr;
     if (rows > 0 && (flags & ASSESS_ALL_BITS)) {
-        const long long gbx = (w + AM_TX - 1) / AM_TX, gby = (rows + AM_TY - 1) / AM_TY;
+        // Blocks are equal work, 3 resident per CU: pick the chunk count that minimises (rounds of blocks) x (rows a
+        // block marches) -- long blocks amortise the 10-row halo, short ones avoid a mostly empty last round on strips.
+        const long long gbx = (w + AM_TX - 1) / AM_TX;
+        const long long slots = (long long)std::max(ctx->num_cu, 1) * 3;
+        long long best_cost = -1;
+        for (int n = 2; n <= AM_NCH_MAX; ++n) {
+            const int ty = AM_CH * n - 2 * AM_R;
+            const long long blocks = gbx * ((rows + ty - 1) / ty);
+            const long long cost = ((blocks + slots - 1) / slots) * (AM_CH * n);
+            if (best_cost < 0 || cost <= best_cost) { best_cost = cost; P.nch = n; P.ty = ty; }
+        }
+        const long long gby = (rows + P.ty - 1) / P.ty;
         const size_t nblk = (size_t)(gbx * gby);
-        const size_t red_doubles = ((nblk + 1023) / 1024 + 1) * 4;
-        auto al = [](size_t v) { return (v + 255) / 256 * 256; };
-        const size_t o_part = 0, o_r0 = o_part + al(nblk * 4 * 8), o_r1 = o_r0 + al(red_doubles * 8),
-                     total = o_r1 + al(red_doubles * 8) + 512;
         void *scr = nullptr;
-        int rc = ctx_scratch(ctx, std::max<size_t>(total, (size_t)8 << 20), &scr);
+        int rc = ctx_scratch(ctx, std::max<size_t>(nblk * 4 * 8 + 512, (size_t)8 << 20), &scr);
         if (rc) return rc;
-        char *base = (char *)scr;
-        double *part = (double *)(base + o_part);
+        double *part = (double *)scr;
         {
             ProfScope ps(ctx, "assess_all");
             if (cn == 3) hipLaunchKernelGGL(k_assess_march<3>, dim3((unsigned)gbx, (unsigned)gby), dim3(256), 0, ctx->stream, d_a, (long long)stride_a, d_b, (long long)stride_b, P, part);
             else hipLaunchKernelGGL(k_assess_march<1>, dim3((unsigned)gbx, (unsigned)gby), dim3(256), 0, ctx->stream, d_a, (long long)stride_a, d_b, (long long)stride_b, P, part);
-            res = reduce_partials(ctx, part, (long long)nblk, 4, (double *)(base + o_r0), (double *)(base + o_r1));
+            hipLaunchKernelGGL(k_assess_finish, dim3(1), dim3(256), 0, ctx->stream, part, (long long)nblk, flags, d_out);
         }
+        return check_launch("assess");
     }
     hipLaunchKernelGGL(k_assess_store, dim3(1), dim3(64), 0, ctx->stream, res, res ? res + 3 : nullptr, flags, d_out);
     return check_launch("assess");

@@ -99,23 +99,59 @@ def workload_geometry(name: str) -> Geometry:
 # ---------------------------------------------------------------------------------------------
 # strip partition + exchange plan (host only; runs identically on every rank)
 # ---------------------------------------------------------------------------------------------
-def strip_bounds(canvas_h: int, world: int, geo: Optional["Geometry"] = None, qa_weight: float = 1.1) -> List[int]:
-    """Strip boundaries.  Without a geometry: equal row counts.  With one: equal *work* -- a canvas row costs the
-    tile pixels covering it (pyramid + gather work; rows inside tile overlaps count twice) plus qa_weight x canvas
-    width for the metrics, so strips through overlap zones get fewer rows.  Boundaries are even (the kernels pair
-    rows) and deterministic on every rank."""
+# Relative cost of the stages per pixel, from the r01_d per-kernel times at 200 MP on MI355X (ps per pixel): what a
+# canvas row costs its strip owner.  Only the ratios matter.
+COST_ASSESS = 10.5     # per canvas pixel (fused PSNR + 3 x SSIM; includes its tail effect on strips)
+COST_GATHER = 4.0      # per tile pixel visited by the canvas gather
+COST_PYRAMID = 6.6     # per tile pixel of the pyramid chains (extract, down, up) -- also paid for the halo rows
+PYRAMID_HALO = 150     # rows of level 0 a strip recomputes beyond each of its borders (6 levels)
+
+
+def strip_bounds(canvas_h: int, world: int, geo: Optional["Geometry"] = None) -> List[int]:
+    """Strip boundaries.  Without a geometry: equal row counts.  With one: equal *work* -- a strip [a, b) costs the
+    assessment and gather work of its own rows plus the pyramid work of rows a - halo .. b + halo (clipped to the
+    canvas: the outer strips recompute a halo on one side only), where a row's tile work is the tile pixels covering
+    it (rows inside tile overlaps count twice).  Found by bisection on the per-strip cost; boundaries are even (the
+    kernels pair rows) and deterministic on every rank."""
     if world <= 1 or geo is None:
         return [canvas_h * r // world for r in range(world + 1)]
-    cost = np.full(canvas_h, qa_weight * geo.canvas_w, dtype=np.float64)
+    cover = np.zeros(canvas_h, dtype=np.float64)
     for (_, y, w, h) in geo.rects:
-        cost[max(y, 0):min(y + h, canvas_h)] += w
-    cum = np.concatenate([[0.0], np.cumsum(cost)])
-    bounds = [0]
-    for r in range(1, world):
-        b = int(np.searchsorted(cum, cum[-1] * r / world))
-        b = min(max(b - (b % 2), bounds[-1] + 2), canvas_h)
-        bounds.append(b)
-    bounds.append(canvas_h)
+        cover[max(y, 0):min(y + h, canvas_h)] += w
+    cum_can = np.concatenate([[0.0], np.cumsum(COST_ASSESS * geo.canvas_w + COST_GATHER * cover)])
+    cum_pyr = np.concatenate([[0.0], np.cumsum(COST_PYRAMID * cover)])
+
+    def cost(a: int, b: int) -> float:
+        lo, hi = max(a - PYRAMID_HALO, 0), min(b + PYRAMID_HALO, canvas_h)
+        return float(cum_can[b] - cum_can[a] + cum_pyr[hi] - cum_pyr[lo])
+
+    def place(target: float) -> List[int]:
+        bounds = [0]
+        for _ in range(world - 1):
+            a = bounds[-1]
+            lo, hi = a + 2, canvas_h              # smallest even b with cost(a, b) >= target
+            while lo < hi:
+                mid = (lo + hi) // 2
+                if cost(a, mid) >= target:
+                    hi = mid
+                else:
+                    lo = mid + 1
+            b = min(lo + (lo % 2), canvas_h)
+            bounds.append(max(b, min(a + 2, canvas_h)))
+        bounds.append(canvas_h)
+        return bounds
+
+    t_lo, t_hi = 0.0, cost(0, canvas_h)
+    for _ in range(60):                           # bisection on the per-strip cost: the last strip absorbs the rest
+        t = 0.5 * (t_lo + t_hi)
+        bnd = place(t)
+        if cost(bnd[-2], canvas_h) > t:
+            t_lo = t
+        else:
+            t_hi = t
+    bounds = place(t_hi)
+    for r in range(1, world + 1):                 # monotone, inside the canvas
+        bounds[r] = min(max(bounds[r], bounds[r - 1]), canvas_h)
     return bounds
 
 
@@ -301,6 +337,7 @@ class DevicePipeline:
         self._pending = None          # exchange work handles of the set in progress (pipeline_*)
         self._reduce_work = []
         self._done = 0                # buffer set holding the last finished step's sums
+        self._first = True
 
     # set 0 under the names the single-step path and the tests use
     @property
@@ -388,6 +425,7 @@ class DevicePipeline:
     def pipeline_begin(self, image):
         """Tile stage + posted exchange of the first image of a stream."""
         self._cur = 0
+        self._first = True
         self.stage_tile(image, 0)
         self._pending = self.stage_exchange(0)
 
@@ -398,11 +436,15 @@ class DevicePipeline:
         order across images changes.  One exchange batch is in flight at any time."""
         k = self._cur
         ptrs, pending = self.sets[k]["ptrs"], self._pending
-        staged = bool(pending)
+        # Only the first image of a stream has its exchange still in flight when its blend starts (worth splitting the
+        # pyramids into held / arriving tiles); later images' rows were moved under the previous image's work, so
+        # they take the monolithic blend: half the kernel launches.
+        staged = bool(pending) and self._first
         if staged:
             self.plan.pyramids(ptrs, self._strides, self._local_needed, first=True)
-            for w in pending:
-                w.wait()
+        for w in pending or ():
+            w.wait()
+        self._first = False
         nk = (k + 1) % len(self.sets)
         overlap = next_image is not None and nk != k
         if overlap:                                       # start image i+1 before the rest of image i
@@ -443,11 +485,15 @@ class DevicePipeline:
         for (_, t, a, b) in self.xplan.recvs(self.rank):
             self.recv_bufs[t].copy_(full_tiles[t][a:b])
 
-    def rehearse_step(self, reference):
-        """Blend (staged, as with an exchange in flight) + assess, without reduce."""
-        self.plan.pyramids(self._ptrs, self._strides, self._local_needed, first=True)
-        self.plan.pyramids(self._ptrs, self._strides, self._remote_needed, first=False)
-        self.plan.gather(self._ptrs, self._strides, self.canvas.data_ptr(), self.canvas.stride(0))
+    def rehearse_step(self, reference, staged: bool = True):
+        """Blend (staged, as with an exchange in flight; or monolithic, as for the later images of a stream) + assess,
+        without reduce."""
+        if staged:
+            self.plan.pyramids(self._ptrs, self._strides, self._local_needed, first=True)
+            self.plan.pyramids(self._ptrs, self._strides, self._remote_needed, first=False)
+            self.plan.gather(self._ptrs, self._strides, self.canvas.data_ptr(), self.canvas.stride(0))
+        else:
+            self.plan.blend(self._ptrs, self._strides, self.canvas.data_ptr(), self.canvas.stride(0))
         self.stage_assess(reference)
         self._done = 0
 
