@@ -81,6 +81,10 @@ typedef struct sr_prof_record {
     int64_t launches;
 } sr_prof_record;
 SR_API int sr_prof_enable(sr_ctx *ctx, int on);
+/* Restricts the timing to one kernel family (NULL or "": all families).  Every timed family costs two event
+ * records per call, which serialise neighbouring kernels: bench.py times only the dominant kernel in its timed
+ * region and all families in a separate pass. */
+SR_API int sr_prof_select(sr_ctx *ctx, const char *name);
 SR_API int sr_prof_reset(sr_ctx *ctx);
 SR_API int sr_prof_get(sr_ctx *ctx, sr_prof_record *h_records, int cap, int *n);
 

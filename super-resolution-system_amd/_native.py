@@ -76,6 +76,7 @@ SIGNATURES = {
     "sr_memcpy_d2d": (_i, [_vp, _vp, _vp, _sz]),
     "sr_memset_d": (_i, [_vp, _vp, _i, _sz]),
     "sr_prof_enable": (_i, [_vp, _i]),
+    "sr_prof_select": (_i, [_vp, C.c_char_p]),
     "sr_prof_reset": (_i, [_vp]),
     "sr_prof_get": (_i, [_vp, C.POINTER(ProfRecord), _i, _pi]),
     "sr_tile_plan": (_i, [_i, _i, _i, _i, _pi, _pi, _i]),
@@ -328,6 +329,10 @@ class Context:
     # profiling ------------------------------------------------------------------------
     def prof_enable(self, on: bool = True):
         check(self.lib.sr_prof_enable(self.handle, 1 if on else 0))
+
+    def prof_select(self, name: Optional[str] = None):
+        """Time only this kernel family (None: all)."""
+        check(self.lib.sr_prof_select(self.handle, name.encode() if name else None))
 
     def prof_reset(self):
         check(self.lib.sr_prof_reset(self.handle))

@@ -58,6 +58,7 @@ struct sr_ctx {
     bool own_stream = false;
     std::recursive_mutex mu;
     bool prof = false;
+    std::string prof_only;          // when not empty: the one kernel family that is timed
     std::vector<std::string> prof_names;
     std::vector<ProfPair> prof_pairs;
     std::vector<hipEvent_t> ev_pool;
@@ -186,6 +187,7 @@ struct ProfScope {
     bool on;
     ProfScope(sr_ctx *ctx, const char *name) : c(ctx), on(ctx->prof)
     {
+        if (on && !c->prof_only.empty() && c->prof_only != name) on = false;
         if (!on) return;
         int id = -1;
         for (size_t i = 0; i < c->prof_names.size(); ++i)
@@ -2215,6 +2217,13 @@ int sr_prof_enable(sr_ctx *ctx, int on)
 {
     CTX_ENTER(ctx);
     ctx->prof = on != 0;
+    return SR_OK;
+}
+
+int sr_prof_select(sr_ctx *ctx, const char *name)
+{
+    CTX_ENTER(ctx);
+    ctx->prof_only = name ? name : "";
     return SR_OK;
 }
 
