@@ -257,6 +257,56 @@ def test_full_size_200mp_properties():
     pipe.close()
 
 
+def test_gigapixel_properties():
+    """Maximum-size case (0.92 GP canvas, 49 tiles of 6200 x 4400, 1.34 G tile pixels, a 17 GB pyramid arena whose
+    float offsets exceed 2^31): (1) the canvas of two strip plans equals the monolithic one bit for bit, (2) the
+    exact SSE equals an independent integer sum computed with torch, (3) every canvas pixel covered by a tile
+    interior is written (no untouched holes), (4) SSIM(x, x) = 1."""
+    import torch
+    import _native
+    import device_pipeline as dp
+    geo = dp.grid_geometry(tile_w=6200, tile_h=4400, rows=7, cols=7, ov_x=1240, ov_y=880)
+    H, W = geo.canvas_h, geo.canvas_w
+    assert H * W > 900e6
+    pipe = dp.DevicePipeline(geo, 0, 1, 0)
+    ctx = pipe.ctx
+    g = torch.Generator(device="cuda").manual_seed(9)
+    small = torch.randint(0, 256, (H // 8 + 2, (W // 8 + 2) * 3), dtype=torch.uint8, device="cuda", generator=g)
+    image = torch.empty((H, W * 3), dtype=torch.uint8, device="cuda")
+    ctx.resize_cubic_u8(small.data_ptr(), small.stride(0), small.shape[0], small.shape[1] // 3, 3, image.data_ptr(), W * 3, H, W)
+    del small
+    reference = torch.roll(image, shifts=3, dims=1)            # the same picture one pixel to the right
+    pipe.canvas.fill_(7)
+    pipe.step(image, reference)
+    torch.cuda.synchronize()
+    m = pipe.metrics()
+    # (2) SSE against torch, in row chunks to bound the int64 temporaries
+    want = 0
+    for a in range(0, H, 2048):
+        d = pipe.canvas[a:a + 2048].to(torch.int32) - reference[a:a + 2048].to(torch.int32)
+        want += int((d * d).sum(dtype=torch.int64))
+    assert int(round(float(pipe.results[0]))) == want
+    assert m["psnr"] == _native.psnr_from_sse(want, H * W * 3)
+    # (3) away from the outermost tile ring (weight 0 there: the reference writes 0) nothing keeps the fill value
+    inner = pipe.canvas.view(H, W, 3)[4:-4, 4:-4]
+    assert float((inner == 7).all(dim=2).float().mean()) < 1e-3
+    # (4)
+    s_, n_ = ctx.ssim_u8(pipe.canvas.data_ptr(), W * 3, pipe.canvas.data_ptr(), W * 3, H, W, 3, "gauss")
+    assert abs(s_ / n_ - 1.0) < 1e-12
+    # (1) two strips
+    mono = pipe.canvas.clone()
+    xp = dp.make_exchange_plan(geo, 2)
+    pipe.canvas.zero_()
+    for r in range(2):
+        a, b = xp.bounds[r], xp.bounds[r + 1]
+        plan = _native.BlendPlan(ctx, geo.rects, 3, H, W, geo.levels, geo.weight_type, a, b)
+        plan.blend(pipe._ptrs, pipe._strides, pipe.canvas.data_ptr(), pipe.canvas.stride(0))
+        torch.cuda.synchronize()
+        plan.close()
+    assert torch.equal(pipe.canvas, mono)
+    pipe.close()
+
+
 def test_device_pipeline_stream_equals_single_steps(rng):
     """pipeline_begin / pipeline_step over a stream of different images gives, image by image, the canvas and sums of
     step() (bench.py times the stream form)."""
