@@ -2,7 +2,7 @@
 """bench.py -- megapixels/sec of tile + blend + QA on a synthetic 720p -> 200 MP job (BASELINE.json).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 200MP|150MP|100MP|4MP|200MP-kd ...]
-                    [--mode strips|batch] [--pcie]
+                    [--mode strips|batch] [--no-pcie]
 
 One process per GPU (N > 1: launched by torch.distributed.run, RCCL over xGMI).  A "step" is one
 pass of the hot path over one synthetic image: overlap-tile extract of the 5x5 tile grid from the
@@ -137,7 +137,8 @@ def main() -> int:
     ap.add_argument("--mode", default="strips", choices=["strips", "batch"],
                     help="strips: one image over all ranks (strong scaling, the BASELINE metric); "
                          "batch: one image per rank, no data-path communication (config 4, weak scaling)")
-    ap.add_argument("--pcie", action="store_true", help="also time host->device of the inputs and device->host of the canvas")
+    ap.add_argument("--no-pcie", action="store_true",
+                    help="skip the host->device (inputs) / device->host (canvas) timing that N=1 runs report beside the resident rate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-kernel HIP-event timing")
     args = ap.parse_args()
@@ -255,7 +256,7 @@ def main() -> int:
     metrics = pipe.metrics()
 
     pcie = None
-    if args.pcie and rank == 0:
+    if world == 1 and not args.no_pcie:
         # the boundary's host-buffer variant: inputs uploaded, canvas downloaded (pinned host memory); never `value`
         h_in = torch.empty((2, H, W * cn), dtype=torch.uint8).pin_memory()
         h_out = torch.empty((H, W * cn), dtype=torch.uint8).pin_memory()

@@ -8,10 +8,10 @@ OUT=gpurun_out/profiles_$TAG
 export TMPDIR=/tmp
 rm -rf "$OUT"; mkdir -p "$OUT"
 python3 bench.py --steps 20 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err" || echo "bench failed"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline \
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-pcie \
     > "$OUT/bench_under_trace.json" 2> "$OUT/trace.err" || echo "trace failed"
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$C" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-prof \
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$C" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-prof --no-pcie \
       > /dev/null 2> "$OUT/pmc_$C.err" || echo "pmc $C failed"
 done
 find "$OUT" -name "*_kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;

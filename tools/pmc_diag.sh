@@ -9,7 +9,7 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 i=0
 for GROUP in "VALUBusy MemUnitStalled" "OccupancyPercent VALUUtilization" "VmemLatency SQ_WAIT_INST_ANY SQ_WAVE_CYCLES" "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_BUSY_CYCLES"; do
   i=$((i+1))
-  rocprofv3 --pmc $GROUP --kernel-trace --output-format csv -d "$OUT/g$i" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof \
+  rocprofv3 --pmc $GROUP --kernel-trace --output-format csv -d "$OUT/g$i" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof --no-pcie \
       > /dev/null 2> "$OUT/g$i.err" || echo "group $i failed"
 done
 python3 - "$OUT" <<'PY'
