@@ -184,3 +184,49 @@ def test_staged_blend_equals_monolithic(ctx, rng):
     plan2.gather(ptrs, strides, c2.ptr, W * 3)
     assert np.array_equal(ctx.download(c2.ptr, (H, W, 3), np.uint8), mono)
     plan.close(); plan2.close()
+
+
+def test_plan_reuse_with_changing_tile_buffers(ctx, rng):
+    """One plan, several calls whose tile pointers / strides / subsets change between calls: the descriptor tables are
+    uploaded only when they change (cached host shadows), so every change must be picked up -- each result equals the
+    oracle's for the tiles actually passed.  Also the tile extract with changing rectangles on one context."""
+    import _native
+    rects = [(0, 0, 160, 120), (120, 10, 160, 120), (60, 90, 160, 120)]
+    H, W = 210, 280
+    plan = _native.BlendPlan(ctx, rects, 3, H, W, 5, "cosine")
+    canvas = ctx.alloc(H * W * 3)
+    pos = [(r[1], r[0]) for r in rects]
+    sets = []
+    for k in range(3):
+        tiles = _tiles(rng, 3, 120, 160)
+        if k == 2:                                        # same pixels as set 1, but padded rows (other strides)
+            tiles = [t.copy() for t in sets[1][0]]
+            padded = [np.zeros((120, 160 + 7, 3), np.uint8) for _ in tiles]
+            for p_, t in zip(padded, tiles):
+                p_[:, :160] = t
+            bufs = [ctx.upload(p_) for p_ in padded]
+            strides = [(160 + 7) * 3] * 3
+        else:
+            bufs = [ctx.upload(t) for t in tiles]
+            strides = [160 * 3] * 3
+        sets.append((tiles, bufs, strides))
+    for order in ([0, 1, 0, 2, 1], ):
+        for k in order:
+            tiles, bufs, strides = sets[k]
+            ptrs = [b.ptr for b in bufs]
+            if k == 1:                                    # staged form with alternating subsets
+                plan.pyramids(ptrs, strides, [2, 0], first=True)
+                plan.pyramids(ptrs, strides, [1], first=False)
+                plan.gather(ptrs, strides, canvas.ptr, W * 3)
+            else:
+                plan.blend(ptrs, strides, canvas.ptr, W * 3)
+            got = ctx.download(canvas.ptr, (H, W, 3), np.uint8)
+            assert np.array_equal(got, oc.laplacian_fusion(tiles, pos, (H, W), 5, "cosine")), k
+    plan.close()
+    img = rng.integers(0, 256, (90, 140, 3), dtype=np.uint8)
+    d_img = ctx.upload(img)
+    for xywh in ([(0, 0, 50, 40), (30, 20, 64, 48)], [(10, 5, 50, 40), (30, 20, 64, 48)], [(10, 5, 50, 40)]):
+        outs = [ctx.alloc(w * h * 3) for (_, _, w, h) in xywh]
+        ctx.tile_extract(d_img.ptr, 90, 140, 3, 140 * 3, xywh, [o.ptr for o in outs], [w * 3 for (_, _, w, _) in xywh])
+        for (x, y, w, h), o in zip(xywh, outs):
+            assert np.array_equal(ctx.download(o.ptr, (h, w, 3), np.uint8), img[y:y + h, x:x + w])
