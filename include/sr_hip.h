@@ -265,6 +265,16 @@ SR_API int sr_assess_u8_async(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a,
 SR_API int sr_assess_u8(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uint8_t *d_b,
                         int64_t stride_b, int h, int w, int cn, int gray_shift, double data_range,
                         int row_begin, int row_end, int flags, sr_assess_sums *h_out);
+/* The same sums taken on the cv2.INTER_CUBIC resize of both images to dst_h x dst_w, sampled on the fly -- the
+ * resized images are never written to memory.  One call per scale replaces downsample_bicubic x 2 + PSNR + SSIM of
+ * QualityAssessmentModule._evaluate_downsample_comparison (quality_assessment_module.py:518-555, 226-253).
+ * a, b: h x w x cn u8; divide by sr_ssim_count(dst_h, dst_w, ...) / (dst_h * dst_w * cn). */
+SR_API int sr_assess_resized_u8_async(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uint8_t *d_b,
+                                      int64_t stride_b, int h, int w, int cn, int dst_h, int dst_w,
+                                      int gray_shift, double data_range, int flags, sr_assess_sums *d_out);
+SR_API int sr_assess_resized_u8(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uint8_t *d_b,
+                                int64_t stride_b, int h, int w, int cn, int dst_h, int dst_w, int gray_shift,
+                                double data_range, int flags, sr_assess_sums *h_out);
 /* number of SSIM-map samples of `mode` inside rows [row_begin,row_end) (host only) */
 SR_API int sr_ssim_count(int h, int w, int mode, int row_begin, int row_end, uint64_t *count);
 /* cv2.cvtColor(RGB2GRAY) on u8 (quality_assessment_module.py:359-360) */

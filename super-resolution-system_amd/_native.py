@@ -113,6 +113,8 @@ SIGNATURES = {
     "sr_ssim_u8_async": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _dbl, _i, _i, _vp, C.POINTER(C.c_uint64)]),
     "sr_assess_u8_async": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _dbl, _i, _i, _i, _vp]),
     "sr_assess_u8": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _dbl, _i, _i, _i, C.POINTER(AssessSums)]),
+    "sr_assess_resized_u8_async": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _dbl, _i, _vp]),
+    "sr_assess_resized_u8": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _dbl, _i, C.POINTER(AssessSums)]),
     "sr_ssim_count": (_i, [_i, _i, _i, _i, _i, C.POINTER(C.c_uint64)]),
     "sr_rgb2gray_u8": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _i64]),
     "sr_resize_cubic_u8": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _i64, _i, _i]),
@@ -423,6 +425,15 @@ class Context:
         check(self.lib.sr_assess_u8(self.handle, C.c_void_p(d_a), stride_a, C.c_void_p(d_b), stride_b, h, w, cn,
                                     gray_shift, data_range, row_begin, h if row_end is None else row_end, flags,
                                     C.byref(out)))
+        return {"sse": out.sse, "ssim_uniform": out.ssim_uniform, "ssim_gauss": out.ssim_gauss,
+                "ssim_simple": out.ssim_simple}
+
+    def assess_resized_u8(self, d_a, stride_a, d_b, stride_b, h, w, cn, dst_h, dst_w, flags=ASSESS_SSE | ASSESS_UNIFORM7,
+                          gray_shift=15, data_range=255.0) -> dict:
+        """The assess_u8 sums taken on the INTER_CUBIC resize of both images to dst_h x dst_w (sampled on the fly)."""
+        out = AssessSums()
+        check(self.lib.sr_assess_resized_u8(self.handle, C.c_void_p(d_a), stride_a, C.c_void_p(d_b), stride_b, h, w, cn,
+                                            dst_h, dst_w, gray_shift, data_range, flags, C.byref(out)))
         return {"sse": out.sse, "ssim_uniform": out.ssim_uniform, "ssim_gauss": out.ssim_gauss,
                 "ssim_simple": out.ssim_simple}
 

@@ -68,6 +68,7 @@ struct sr_ctx {
     // host copies of small tables handed to hipMemcpyAsync; released at the next stream sync
     std::vector<std::vector<char>> pending_host;
     CachedTable extract_tab;                            // tile-extract descriptors
+    CachedTable resize_tab;                             // cubic tables of the resized assessment
 };
 
 // Enqueue a small host->device table upload whose source stays alive until the next sync.
@@ -1576,11 +1577,21 @@ __global__ __launch_bounds__(256) void k_rgb2gray(const unsigned char *__restric
 // and x*y are ints, symmetric taps are pair-summed as ints and only 6 products per map are formed.  4 filtered maps
 // (x, y, x^2 + y^2, x*y) replace the reference's 5: SSIM needs uxx and uyy only as their sum.
 // ---------------------------------------------------------------------------------------------
+// cv2.resize INTER_CUBIC, u8: per destination index the first source tap and four 11-bit fixed-point coefficients
+struct CubicTab {
+    int ofs;
+    short c[4];
+};
+
 enum { ASSESS_SSE = 1, ASSESS_UNIFORM = 2, ASSESS_GAUSS = 4, ASSESS_SIMPLE = 8, ASSESS_ALL_BITS = 15 };
 
 struct AssessParams {
     int h, w, shift, ry0, ry1, flags, same_c;
     int nch, ty;       // chunks of 11 rows a block marches, and the rows it produces (11 nch - 10)
+    // resized assessment (sr_assess_resized_u8): h, w above are the RESIZED size the metrics are taken on; the images
+    // behind a / b are sh x sw and every pixel is the cv2.INTER_CUBIC sample through these tables (else null)
+    int sh, sw;
+    const CubicTab *xt, *yt;
     double c1a, c2a;   // constants for data_range (uniform / gauss)
     double c1b, c2b;   // constants for 255 (simple)
     double k[6];       // k[0] centre tap, k[j] the +-j taps
@@ -1649,9 +1660,49 @@ __device__ __forceinline__ double ssim_value(double ux, double uy, double spq, d
 #define AM_NCH_MAX 12                   /* chunks per block: P.nch <= 12, chosen per launch (rows / tail effect) */
 /* a block marches 11 * nch rows and produces P.ty = 11 * nch - 10 of them; LDS 36 KB + 14 KB ring -> 3 blocks per CU */
 
+// cv2.resize(INTER_CUBIC) sample of one destination pixel (all channels) -- the arithmetic of k_resize_cubic
+template <int CN>
+__device__ __forceinline__ void cubic_sample(const unsigned char *__restrict__ src, long long sstride, int sh, int sw,
+                                             const CubicTab X, const CubicTab Y, int (&out)[CN])
+{
+    long long acc[CN];
+#pragma unroll
+    for (int c = 0; c < CN; ++c) acc[c] = 0;
+    const bool inner = X.ofs - 1 >= 0 && X.ofs + 2 <= sw - 1;
+    const short yc[4] = {Y.c[0], Y.c[1], Y.c[2], Y.c[3]};
+#pragma unroll 2
+    for (int ky = 0; ky < 4; ++ky) {
+        const unsigned char *r = src + (size_t)min(max(Y.ofs + ky - 1, 0), sh - 1) * sstride;
+        int v[4][CN];
+        if (inner && CN == 3) {
+            const u3_t q = ld_u3_a1(r + (size_t)(X.ofs - 1) * 3);
+            const unsigned wd[3] = {q.x, q.y, q.z};
+#pragma unroll
+            for (int b = 0; b < 12; ++b) v[b / 3][b % 3] = (int)((wd[b >> 2] >> (8 * (b & 3))) & 0xFFu);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int sx = min(max(X.ofs + k - 1, 0), sw - 1) * CN;
+#pragma unroll
+                for (int c = 0; c < CN; ++c) v[k][c] = (int)r[sx + c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CN; ++c) {
+            const int hs = v[0][c] * X.c[0] + v[1][c] * X.c[1] + v[2][c] * X.c[2] + v[3][c] * X.c[3];
+            acc[c] += (long long)hs * yc[ky];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CN; ++c) {
+        const long long t = (acc[c] + (1 << 21)) >> 22;
+        out[c] = (int)(t < 0 ? 0 : (t > 255 ? 255 : t));
+    }
+}
+
 // gray conversion + per-pixel products of 4-pixel groups of chunk `ch` into LDS; returns this thread's share of the
 // squared differences of the block's own pixels
-template <int CN>
+template <int CN, bool RESIZE>
 __device__ __forceinline__ unsigned long long assess_load_chunk(const unsigned char *__restrict__ a, long long sa,
                                                                 const unsigned char *__restrict__ b, long long sb,
                                                                 const AssessParams &P, int bx0, int by0, int ch,
@@ -1660,6 +1711,38 @@ __device__ __forceinline__ unsigned long long assess_load_chunk(const unsigned c
 {
     unsigned long long sse = 0;
     const bool want_sse = (P.flags & ASSESS_SSE) != 0;
+    if (RESIZE) {
+        // one resized pixel per step, both images, kept as a rolled loop: the sampling (4 rows x 4 taps x CN, 64-bit
+        // accumulators) is register-hungry and the march that follows needs its 150 VGPRs for three waves per SIMD
+#pragma unroll 1
+        for (int i = threadIdx.x; i < AM_CH * AM_GP; i += 256) {
+            const int ly = i / AM_GP, lx = i - ly * AM_GP;
+            const int lr = ch * AM_CH + ly;
+            if (lr >= rows_needed) break;
+            const int gy = by0 - AM_R + lr, gx = bx0 - AM_R + lx;
+            const CubicTab Y = P.yt[reflect101(gy, P.h)], X = P.xt[reflect101(gx, P.w)];
+            int va[CN], vb[CN];
+            cubic_sample<CN>(a, sa, P.sh, P.sw, X, Y, va);
+            cubic_sample<CN>(b, sb, P.sh, P.sw, X, Y, vb);
+            int ga, gb;
+            if (CN == 3) {
+                ga = gray_rgb(va[0], va[1], va[2], P.shift);
+                gb = gray_rgb(vb[0], vb[1], vb[2], P.shift);
+            } else {
+                ga = va[0];
+                gb = vb[0];
+            }
+            XY[ly][lx] = (unsigned)ga | ((unsigned)gb << 16);
+            QQ[ly][lx] = (unsigned)__mul24(ga, gb);
+            PP[ly][lx] = (unsigned)(__mul24(ga, ga) + __mul24(gb, gb));
+            if (want_sse && lr >= AM_R && lr < AM_R + P.ty && gy < P.ry1 && gy < P.h && lx >= AM_R && lx < AM_R + AM_TX &&
+                gx < P.w) {
+#pragma unroll
+                for (int c = 0; c < CN; ++c) sse += (unsigned)((va[c] - vb[c]) * (va[c] - vb[c]));
+            }
+        }
+        return sse;
+    }
     for (int i = threadIdx.x; i < AM_CH * (AM_GP / 4); i += 256) {
         const int ly = i / (AM_GP / 4), lx = (i - ly * (AM_GP / 4)) * 4;
         const int lr = ch * AM_CH + ly;
@@ -1724,7 +1807,8 @@ __device__ __forceinline__ unsigned long long assess_load_chunk(const unsigned c
     return sse;
 }
 
-template <int CN>
+// GAUSS = false drops the Gaussian variants at compile time (no 88-register FIFO): SSE and / or uniform-7 only.
+template <int CN, bool RESIZE, bool GAUSS>
 __global__ __launch_bounds__(256) void k_assess_march(const unsigned char *__restrict__ a, long long sa,
                                                       const unsigned char *__restrict__ b, long long sb,
                                                       AssessParams P, double *__restrict__ part)
@@ -1739,7 +1823,7 @@ __global__ __launch_bounds__(256) void k_assess_march(const unsigned char *__res
     const int rows_needed = min(P.ty, P.ry1 - by0) + 2 * AM_R;          // block-uniform
     const int mx = bx0 + c;
     const bool col_ok = mx < P.w;
-    const bool do_u = (P.flags & ASSESS_UNIFORM) != 0, do_g = (P.flags & (ASSESS_GAUSS | ASSESS_SIMPLE)) != 0;
+    const bool do_u = (P.flags & ASSESS_UNIFORM) != 0, do_g = GAUSS && (P.flags & (ASSESS_GAUSS | ASSESS_SIMPLE)) != 0;
     const bool u_col = mx >= 3 && mx < P.w - 3, g_col = mx >= AM_R && mx < P.w - AM_R;
     double f[4][11];
 #pragma unroll
@@ -1755,7 +1839,7 @@ __global__ __launch_bounds__(256) void k_assess_march(const unsigned char *__res
     for (int ch = 0; ch < P.nch; ++ch) {
         if (ch * AM_CH >= rows_needed) break;
         __syncthreads();                                                // the previous chunk has been read
-        sse += assess_load_chunk<CN>(a, sa, b, sb, P, bx0, by0, ch, rows_needed, XY, QQ, PP);
+        sse += assess_load_chunk<CN, RESIZE>(a, sa, b, sb, P, bx0, by0, ch, rows_needed, XY, QQ, PP);
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < AM_CH; ++s) {
@@ -1877,10 +1961,6 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const double *__restric
 // ---------------------------------------------------------------------------------------------
 // cv2.resize INTER_CUBIC, u8
 // ---------------------------------------------------------------------------------------------
-struct CubicTab {
-    int ofs;
-    short c[4];
-};
 
 __global__ __launch_bounds__(256) void k_resize_cubic(const unsigned char *__restrict__ src, long long sstride,
                                                       int h, int w, int cn, const CubicTab *__restrict__ xt,
@@ -2145,6 +2225,7 @@ int sr_ctx_destroy(sr_ctx *ctx)
         for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
         if (ctx->scratch) (void)hipFree(ctx->scratch);
         if (ctx->extract_tab.d) (void)hipFree(ctx->extract_tab.d);
+        if (ctx->resize_tab.d) (void)hipFree(ctx->resize_tab.d);
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;
@@ -3318,15 +3399,18 @@ int sr_ssim_count(int h, int w, int mode, int row_begin, int row_end, uint64_t *
     return SR_OK;
 }
 
-int sr_assess_u8_async(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uint8_t *d_b, int64_t stride_b, int h,
+// Shared body of sr_assess_u8_async / sr_assess_resized_u8_async.  (h, w): the image the metrics are taken on; with
+// src_h > 0 the buffers are src_h x src_w and that image is their cv2.INTER_CUBIC resize, sampled on the fly.
+static int assess_impl(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uint8_t *d_b, int64_t stride_b, int h,
                        int w, int cn, int gray_shift, double data_range, int row_begin, int row_end, int flags,
-                       sr_assess_sums *d_out)
+                       sr_assess_sums *d_out, int src_h, int src_w, const char *scope)
 {
-    CTX_ENTER(ctx);
-    if (!d_a || !d_b || !d_out) return sr_set_error(SR_ERR_INVALID_ARG, "sr_assess_u8: null argument");
-    if (h < 1 || w < 1 || (cn != 1 && cn != 3)) return sr_set_error(SR_ERR_INVALID_ARG, "sr_assess_u8: need h,w >= 1 and 1 or 3 channels");
-    if (gray_shift != 14 && gray_shift != 15) return sr_set_error(SR_ERR_INVALID_ARG, "sr_assess_u8: gray_shift must be 14 or 15");
-    if (stride_a < (int64_t)w * cn || stride_b < (int64_t)w * cn) return sr_set_error(SR_ERR_SHAPE, "sr_assess_u8: stride smaller than a row");
+    const bool resized = src_h > 0;
+    if (!d_a || !d_b || !d_out) return sr_set_error(SR_ERR_INVALID_ARG, "%s: null argument", scope);
+    if (h < 1 || w < 1 || (cn != 1 && cn != 3)) return sr_set_error(SR_ERR_INVALID_ARG, "%s: need h,w >= 1 and 1 or 3 channels", scope);
+    if (gray_shift != 14 && gray_shift != 15) return sr_set_error(SR_ERR_INVALID_ARG, "%s: gray_shift must be 14 or 15", scope);
+    const int64_t min_stride = (int64_t)(resized ? src_w : w) * cn;
+    if (stride_a < min_stride || stride_b < min_stride) return sr_set_error(SR_ERR_SHAPE, "%s: stride smaller than a row", scope);
     row_begin = std::max(row_begin, 0);
     row_end = std::min(row_end, h);
     AssessParams P;
@@ -3339,8 +3423,18 @@ int sr_assess_u8_async(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const 
     P.same_c = (P.c1a == P.c1b && P.c2a == P.c2b) ? 1 : 0;
     gauss_taps(P.k);
     const int rows = row_end - row_begin;
-    const double *res = nullptr;
     if (rows > 0 && (flags & ASSESS_ALL_BITS)) {
+        if (resized) {
+            // both axes' tables in one cached device table (re-used while the geometry stays the same)
+            std::vector<CubicTab> xt, yt;
+            cubic_table(src_w, w, xt);
+            cubic_table(src_h, h, yt);
+            xt.insert(xt.end(), yt.begin(), yt.end());
+            HIPCHK(upload_cached(ctx, ctx->resize_tab, xt.data(), sizeof(CubicTab) * xt.size()));
+            P.sh = src_h; P.sw = src_w;
+            P.xt = (const CubicTab *)ctx->resize_tab.d;
+            P.yt = P.xt + w;
+        }
         // Blocks are equal work, 3 resident per CU: pick the chunk count that minimises (rounds of blocks) x (rows a
         // block marches) -- long blocks amortise the 10-row halo, short ones avoid a mostly empty last round on strips.
         const long long gbx = (w + AM_TX - 1) / AM_TX;
@@ -3359,15 +3453,63 @@ int sr_assess_u8_async(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const 
         if (rc) return rc;
         double *part = (double *)scr;
         {
-            ProfScope ps(ctx, "assess_all");
-            if (cn == 3) hipLaunchKernelGGL(k_assess_march<3>, dim3((unsigned)gbx, (unsigned)gby), dim3(256), 0, ctx->stream, d_a, (long long)stride_a, d_b, (long long)stride_b, P, part);
-            else hipLaunchKernelGGL(k_assess_march<1>, dim3((unsigned)gbx, (unsigned)gby), dim3(256), 0, ctx->stream, d_a, (long long)stride_a, d_b, (long long)stride_b, P, part);
+            ProfScope ps(ctx, scope);
+            const dim3 grid((unsigned)gbx, (unsigned)gby), block(256);
+#define LAUNCH_ASSESS(CNV, RS, GS)                                                                                   \
+    hipLaunchKernelGGL((k_assess_march<CNV, RS, GS>), grid, block, 0, ctx->stream, d_a, (long long)stride_a, d_b,       \
+                       (long long)stride_b, P, part)
+#define LAUNCH_ASSESS_G(CNV, RS)                                                                                     \
+    do { if (gauss) LAUNCH_ASSESS(CNV, RS, true); else LAUNCH_ASSESS(CNV, RS, false); } while (0)
+            const bool gauss = (flags & (ASSESS_GAUSS | ASSESS_SIMPLE)) != 0;
+            if (cn == 3) { if (resized) LAUNCH_ASSESS_G(3, true); else LAUNCH_ASSESS_G(3, false); }
+            else         { if (resized) LAUNCH_ASSESS_G(1, true); else LAUNCH_ASSESS_G(1, false); }
+#undef LAUNCH_ASSESS_G
+#undef LAUNCH_ASSESS
             hipLaunchKernelGGL(k_assess_finish, dim3(1), dim3(256), 0, ctx->stream, part, (long long)nblk, flags, d_out);
         }
         return check_launch("assess");
     }
-    hipLaunchKernelGGL(k_assess_store, dim3(1), dim3(64), 0, ctx->stream, res, res ? res + 3 : nullptr, flags, d_out);
+    hipLaunchKernelGGL(k_assess_store, dim3(1), dim3(64), 0, ctx->stream, (const double *)nullptr, (const double *)nullptr, flags, d_out);
     return check_launch("assess");
+}
+
+int sr_assess_u8_async(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uint8_t *d_b, int64_t stride_b, int h,
+                       int w, int cn, int gray_shift, double data_range, int row_begin, int row_end, int flags,
+                       sr_assess_sums *d_out)
+{
+    CTX_ENTER(ctx);
+    return assess_impl(ctx, d_a, stride_a, d_b, stride_b, h, w, cn, gray_shift, data_range, row_begin, row_end, flags,
+                       d_out, 0, 0, "assess_all");
+}
+
+int sr_assess_resized_u8_async(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uint8_t *d_b, int64_t stride_b,
+                               int h, int w, int cn, int dst_h, int dst_w, int gray_shift, double data_range, int flags,
+                               sr_assess_sums *d_out)
+{
+    CTX_ENTER(ctx);
+    if (h < 1 || w < 1 || dst_h < 1 || dst_w < 1)
+        return sr_set_error(SR_ERR_INVALID_ARG, "sr_assess_resized_u8: need positive source and destination sizes");
+    return assess_impl(ctx, d_a, stride_a, d_b, stride_b, dst_h, dst_w, cn, gray_shift, data_range, 0, dst_h, flags, d_out,
+                       h, w, "assess_resized");
+}
+
+int sr_assess_resized_u8(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uint8_t *d_b, int64_t stride_b, int h,
+                         int w, int cn, int dst_h, int dst_w, int gray_shift, double data_range, int flags,
+                         sr_assess_sums *h_out)
+{
+    CTX_ENTER(ctx);
+    if (!h_out) return sr_set_error(SR_ERR_INVALID_ARG, "sr_assess_resized_u8: null result");
+    void *res = nullptr;
+    HIPCHK(hipMalloc(&res, sizeof(sr_assess_sums)));
+    int rc = sr_assess_resized_u8_async(ctx, d_a, stride_a, d_b, stride_b, h, w, cn, dst_h, dst_w, gray_shift,
+                                        data_range, flags, (sr_assess_sums *)res);
+    if (rc == SR_OK) {
+        hipError_t e = hipMemcpyAsync(h_out, res, sizeof(sr_assess_sums), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = stream_sync(ctx);
+        if (e != hipSuccess) rc = sr_set_error(SR_ERR_HIP, "sr_assess_resized_u8: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(res);
+    return rc;
 }
 
 int sr_assess_u8(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uint8_t *d_b, int64_t stride_b, int h, int w,

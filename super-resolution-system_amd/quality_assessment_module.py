@@ -251,10 +251,23 @@ class QualityAssessmentModule:
         try:
             metrics: Dict[str, Any] = {}
             metrics.update(self._downsample_comparison_dev(d_o, d_u))
-            metrics['psnr'] = float(self._psnr_dev(d_o, d_u, 255.0))
+            if d_o.shape == d_u.shape:
+                # PSNR, SSIM and MS-SSIM of the full-size pair from ONE pass over both images (sr_assess_u8)
+                h, w, cn = d_o.h, d_o.w, d_o.cn
+                if self.ssim_branch == 'B':
+                    flags, m1, m2 = _native.ASSESS_SSE | _native.ASSESS_SIMPLE, "simple", "simple"
+                else:
+                    flags, m1, m2 = _native.ASSESS_SSE | _native.ASSESS_UNIFORM7 | _native.ASSESS_GAUSS11, "uniform", "gauss"
+                r = ctx.assess_u8(d_o.ptr, d_o.stride, d_u.ptr, d_u.stride, h, w, cn, flags=flags,
+                                  gray_shift=self.gray_shift)
+                metrics['psnr'] = float(_native.psnr_from_sse(int(round(r["sse"])), h * w * cn, 255.0))
+                metrics['ssim'] = float(r[f"ssim_{m1}"] / _native.ssim_count(h, w, m1))
+                metrics['ms_ssim'] = float(r[f"ssim_{m2}"] / _native.ssim_count(h, w, m2))
+            else:
+                metrics['psnr'] = float(self._psnr_dev(d_o, d_u, 255.0))
+                metrics['ssim'] = float(self._ssim_dev(d_o, d_u, False, 255.0))
+                metrics['ms_ssim'] = float(self._ssim_dev(d_o, d_u, True, 255.0))
             metrics['psnr_level'] = self._assess_psnr(metrics['psnr'])
-            metrics['ssim'] = float(self._ssim_dev(d_o, d_u, False, 255.0))
-            metrics['ms_ssim'] = float(self._ssim_dev(d_o, d_u, True, 255.0))
             metrics['ssim_level'] = self._assess_ssim(metrics['ms_ssim'])
             metrics['overall_score'] = self._calculate_overall_score(metrics)
             return metrics
@@ -267,6 +280,17 @@ class QualityAssessmentModule:
             if scale >= 1.0 or scale <= 0:
                 raise ValueError(f"scale_factor必须在(0, 1)范围内，当前值: {scale}")
             name = self.scale_config.scale_names.get(scale, f"scale_{scale}")
+            if d_o.shape == d_u.shape and int(d_o.h * scale) >= 1 and int(d_o.w * scale) >= 1:
+                # both bicubic resizes, PSNR and SSIM of the resized pair in one kernel: the resized images are
+                # sampled on the fly and never written (sr_assess_resized_u8)
+                dh, dw, cn = int(d_o.h * scale), int(d_o.w * scale), d_o.cn
+                mode = "simple" if self.ssim_branch == 'B' else "uniform"
+                bit = _native.ASSESS_SIMPLE if mode == "simple" else _native.ASSESS_UNIFORM7
+                r = d_o.ctx.assess_resized_u8(d_o.ptr, d_o.stride, d_u.ptr, d_u.stride, d_o.h, d_o.w, cn, dh, dw,
+                                              flags=_native.ASSESS_SSE | bit, gray_shift=self.gray_shift)
+                out[f'psnr_{name}'] = float(_native.psnr_from_sse(int(round(r["sse"])), dh * dw * cn, 255.0))
+                out[f'ssim_{name}'] = float(r[f"ssim_{mode}"] / _native.ssim_count(dh, dw, mode))
+                continue
             sr = self._resize_dev(d_u, int(d_u.h * scale), int(d_u.w * scale))
             hr = self._resize_dev(d_o, int(d_o.h * scale), int(d_o.w * scale))
             out[f'psnr_{name}'] = float(self._psnr_dev(hr, sr, 255.0))

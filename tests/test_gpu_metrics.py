@@ -147,3 +147,36 @@ def test_tile_extract_pad_iterated_reflection(ctx, rng):
         ctx.tile_extract_pad(dimg.ptr, 45, 80, 3, 80 * 3, xywh, block, mode, dt.ptr)
         assert np.array_equal(ctx.download(dt.ptr, (block, block, 3), np.uint8),
                               oc.tile_extract_pad(img, 0, 0, 80, 45, block, mode))
+
+
+@pytest.mark.parametrize("shape,dst", [((300, 411, 3), (111, 152)), ((193, 257, 3), (19, 25)), ((128, 640), (51, 256)),
+                                         ((97, 83, 3), (97, 83)), ((64, 64, 3), (5, 6))])
+def test_assess_resized_equals_resize_then_assess(ctx, rng, shape, dst):
+    """sr_assess_resized_u8 (bicubic resize sampled on the fly inside the metric kernel) gives the
+    sums of sr_resize_cubic_u8 on both images followed by sr_assess_u8 -- and those of the oracle's resize + metrics."""
+    import _native
+    a = rng.integers(0, 256, shape, dtype=np.uint8)
+    b = np.clip(a.astype(np.int16) + rng.integers(-9, 10, shape), 0, 255).astype(np.uint8)
+    h, w = shape[:2]
+    cn = 3 if len(shape) == 3 else 1
+    dh, dw = dst
+    da, db = ctx.upload(a), ctx.upload(b)
+    flags = _native.ASSESS_ALL
+    got = ctx.assess_resized_u8(da.ptr, w * cn, db.ptr, w * cn, h, w, cn, dh, dw, flags=flags)
+    ra, rb = ctx.alloc(dh * dw * cn), ctx.alloc(dh * dw * cn)
+    ctx.resize_cubic_u8(da.ptr, w * cn, h, w, cn, ra.ptr, dw * cn, dh, dw)
+    ctx.resize_cubic_u8(db.ptr, w * cn, h, w, cn, rb.ptr, dw * cn, dh, dw)
+    want = ctx.assess_u8(ra.ptr, dw * cn, rb.ptr, dw * cn, dh, dw, cn, flags=flags)
+    assert got["sse"] == want["sse"]
+    for k in ("ssim_uniform", "ssim_gauss", "ssim_simple"):
+        assert got[k] == pytest.approx(want[k], rel=1e-13, abs=1e-300), k
+    # against the CPU oracle
+    oa, ob = oc.resize_cubic_u8(a, dw, dh), oc.resize_cubic_u8(b, dw, dh)
+    assert got["sse"] == float(np.sum((oa.astype(np.int64) - ob.astype(np.int64)) ** 2))
+    if dh >= 7 and dw >= 7:
+        g0 = oc.rgb2gray_u8(oa) if cn == 3 else oa
+        g1 = oc.rgb2gray_u8(ob) if cn == 3 else ob
+        n = _native.ssim_count(dh, dw, "uniform")
+        assert got["ssim_uniform"] / n == pytest.approx(oc.ssim(g0, g1, "uniform"), rel=1e-9)
+    for buf in (da, db, ra, rb):
+        buf.free()
