@@ -2865,8 +2865,9 @@ static int blend_pyramids(sr_blend_plan *P, int dtype, void *const *h_d_tiles, c
         ProfScope ps(ctx, i == 0 ? "down_l0" : "down_l1p");
         const bool blk = (P->cn == 3 || P->cn == 1) && !(i == 0 && dtype != SR_U8);
         if (blk) {
-            int max_cells = 0, seg_rows = 8;
-            for (int cand = 32; cand >= 8; cand /= 2) {       // longest segments that still give ~8 blocks per CU
+            int max_cells = 0, seg_rows = 2;
+            for (int cand = 32; cand >= 2; cand /= 2) {       // longest segments that still give ~8 blocks per CU;
+                                                              // small levels end at 2 rows: short dependent chains
                 long long total = 0;
                 max_cells = 0;
                 seg_rows = cand;
