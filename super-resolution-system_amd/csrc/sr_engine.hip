@@ -1594,6 +1594,7 @@ struct AssessParams {
     const CubicTab *xt, *yt;
     double c1a, c2a;   // constants for data_range (uniform / gauss)
     double c1b, c2b;   // constants for 255 (simple)
+    double k1u, k2u;   // 49^2 c1a and 48*49 c2a: the uniform-7 variant in integer-scaled form
     double k[6];       // k[0] centre tap, k[j] the +-j taps
 };
 
@@ -1833,7 +1834,6 @@ __global__ __launch_bounds__(256) void k_assess_march(const unsigned char *__res
     int t_xy = 0, t_p = 0, t_q = 0;
     double sum_int = 0.0, sum_all = 0.0, sum_u = 0.0;
     unsigned long long sse = 0;
-    const double inv49 = 1.0 / 49.0, cn49 = 49.0 / 48.0;
     int slot = 0;                                                       // row index mod 7
 #pragma unroll 1
     for (int ch = 0; ch < P.nch; ++ch) {
@@ -1880,12 +1880,17 @@ __global__ __launch_bounds__(256) void k_assess_march(const unsigned char *__res
                     U[slot][1][c] = (int)(up | ((uq >> 10) << 21));
                     const int orow = r - 8, my = by0 + orow;             // window rows r-6 .. r, centre r-3
                     if (orow >= 0 && orow < P.ty && my < P.ry1 && my >= 3 && my < P.h - 3 && u_col) {
-                        const double mux = (double)(t_xy & 0xFFFF) * inv49, muy = (double)((unsigned)t_xy >> 16) * inv49;
-                        const double sxxyy = (double)t_p * inv49;                    // (sum xx + sum yy) / 49, exact integers
-                        const double sxy = (double)t_q * inv49;                      // sum xy / 49
-                        const double uxuy = mux * muy, uu = mux * mux + muy * muy;
-                        const double a1 = 2.0 * uxuy + P.c1a, a2 = 2.0 * (cn49 * (sxy - uxuy)) + P.c2a;
-                        const double b1 = uu + P.c1a, b2 = cn49 * (sxxyy - uu) + P.c2a;
+                        // SSIM of the 49-sample window with both fractions scaled to integers: with S. the window sums,
+                        //   (2 ux uy + C1) / (ux^2 + uy^2 + C1) = (2 Sx Sy + 49^2 C1) / (Sx^2 + Sy^2 + 49^2 C1)
+                        //   (2 cov + C2) / (var_x + var_y + C2) = (2 (49 Sxy - Sx Sy) + 48*49 C2)
+                        //                                         / (49 (Sxx + Syy) - (Sx^2 + Sy^2) + 48*49 C2)
+                        // (sample covariance, N - 1 = 48).  Everything left of the constants is exact 32-bit integer
+                        // arithmetic (|values| < 3.2e8); fp64 enters with the constants.
+                        const int sx = t_xy & 0xFFFF, sy = (int)((unsigned)t_xy >> 16);
+                        const int sxsy = __mul24(sx, sy), ss = __mul24(sx, sx) + __mul24(sy, sy);
+                        const int ncov = 49 * t_q - sxsy, nvar = 49 * t_p - ss;
+                        const double a1 = fma(2.0, (double)sxsy, P.k1u), a2 = fma(2.0, (double)ncov, P.k2u);
+                        const double b1 = (double)ss + P.k1u, b2 = (double)nvar + P.k2u;
                         sum_u += (a1 * a2) * fast_recip(b1 * b2);
                     }
                 }
@@ -3422,6 +3427,8 @@ static int assess_impl(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const 
     P.c1b = (0.01 * 255.0) * (0.01 * 255.0);
     P.c2b = (0.03 * 255.0) * (0.03 * 255.0);
     P.same_c = (P.c1a == P.c1b && P.c2a == P.c2b) ? 1 : 0;
+    P.k1u = 2401.0 * P.c1a;
+    P.k2u = 2352.0 * P.c2a;
     gauss_taps(P.k);
     const int rows = row_end - row_begin;
     if (rows > 0 && (flags & ASSESS_ALL_BITS)) {
