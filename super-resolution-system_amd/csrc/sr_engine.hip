@@ -1852,23 +1852,32 @@ __global__ __launch_bounds__(256) void k_assess_march(const unsigned char *__res
                     qv[j] = QQ[s][c + j];
                     pv[j] = PP[s][c + j];
                 }
+                // symmetric pair sums, shared by the Gaussian row pass (all five) and the 7-tap box sums (the first three)
+                unsigned sxy[6], sp[6], sq[6];
+                sxy[0] = xy[5]; sp[0] = pv[5]; sq[0] = qv[5];
+#pragma unroll
+                for (int j = 1; j <= AM_R; ++j) {
+                    if (j > 3 && !do_g) continue;
+                    sxy[j] = xy[5 - j] + xy[5 + j];                 // both pair sums in one add (each < 2^16)
+                    sp[j] = pv[5 - j] + pv[5 + j];
+                    sq[j] = qv[5 - j] + qv[5 + j];
+                }
                 if (do_g) {
-                    double hx = (double)(xy[5] & 0xFFFFu) * P.k[0], hy = (double)(xy[5] >> 16) * P.k[0];
-                    double hp = (double)pv[5] * P.k[0], hq = (double)qv[5] * P.k[0];
+                    double hx = (double)(sxy[0] & 0xFFFFu) * P.k[0], hy = (double)(sxy[0] >> 16) * P.k[0];
+                    double hp = (double)sp[0] * P.k[0], hq = (double)sq[0] * P.k[0];
 #pragma unroll
                     for (int j = 1; j <= AM_R; ++j) {
-                        const unsigned sxy = xy[5 - j] + xy[5 + j];     // both pair sums in one add (each < 2^16)
-                        hx = fma((double)(sxy & 0xFFFFu), P.k[j], hx);
-                        hy = fma((double)(sxy >> 16), P.k[j], hy);
-                        hp = fma((double)(pv[5 - j] + pv[5 + j]), P.k[j], hp);
-                        hq = fma((double)(qv[5 - j] + qv[5 + j]), P.k[j], hq);
+                        hx = fma((double)(sxy[j] & 0xFFFFu), P.k[j], hx);
+                        hy = fma((double)(sxy[j] >> 16), P.k[j], hy);
+                        hp = fma((double)sp[j], P.k[j], hp);
+                        hq = fma((double)sq[j], P.k[j], hq);
                     }
                     f[0][s] = hx; f[1][s] = hy; f[2][s] = hp; f[3][s] = hq;
                 }
                 if (do_u) {
-                    unsigned uxy = 0, up = 0, uq = 0;
-#pragma unroll
-                    for (int j = 2; j <= 8; ++j) { uxy += xy[j]; up += pv[j]; uq += qv[j]; }
+                    const unsigned uxy = ((sxy[0] + sxy[1]) + sxy[2]) + sxy[3];
+                    const unsigned up = ((sp[0] + sp[1]) + sp[2]) + sp[3];
+                    const unsigned uq = ((sq[0] + sq[1]) + sq[2]) + sq[3];
                     if (r >= 7) {
                         const unsigned o0 = (unsigned)U[slot][0][c], o1 = (unsigned)U[slot][1][c];
                         t_xy -= (int)((o0 & 0x7FFu) | (((o0 >> 11) & 0x7FFu) << 16));
