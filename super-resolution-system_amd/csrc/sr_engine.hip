@@ -872,24 +872,7 @@ __device__ __forceinline__ void gather_tile_fast(const FinalDesc &D, const float
                                                  float (&acc)[2][4][CN], float (&wacc)[2][4])
 {
     const bool pyr = LAP && D.nl > 1;
-    // ---- loads -----------------------------------------------------------------------------------------
-    f4_t qg[CN][3], qr[CN][3];
-    if (pyr) {
-        const int r0 = (ly0 - 1) >> 1, c0 = (lx0 - 1) >> 1;
-        const size_t splane = (size_t)D.H1 * D.P1;
-        const unsigned rowb = (unsigned)D.P1 * 4u;
-        const unsigned o = (unsigned)r0 * rowb + (unsigned)c0 * 4u;      // byte offset inside a plane (planes < 4 GB)
-#pragma unroll
-        for (int c = 0; c < CN; ++c) {
-            const char *gb = (const char *)(arena + D.g1 + c * splane);
-            const char *rb = (const char *)(arena + D.r1 + c * splane);
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                qg[c][r] = ld_f4_a4((const float *)(gb + (o + r * rowb)));
-                qr[c][r] = ld_f4_a4((const float *)(rb + (o + r * rowb)));
-            }
-        }
-    }
+    // ---- loads of the level-0 pixels and the weights ------------------------------------------------------
     float g0[2][4][CN];
     u3_t qs[2];
 #pragma unroll
@@ -909,7 +892,6 @@ __device__ __forceinline__ void gather_tile_fast(const FinalDesc &D, const float
     }
     float w0[2][4];
     tile_weights_interior(D, luts, lx0, ly0, w0);
-    // ---- arithmetic ----------------------------------------------------------------------------------------
     if (DT == SRC_U8 && CN == 3) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -919,11 +901,35 @@ __device__ __forceinline__ void gather_tile_fast(const FinalDesc &D, const float
         }
     }
     if (pyr) {                               // tile-uniform: a real branch, not a select per value
+        // plane by plane: the six 16-byte loads of a plane are in flight together, the next plane's are issued
+        // before this plane's arithmetic (two planes of level-1 data live at a time, not three)
+        const int r0 = (ly0 - 1) >> 1, c0 = (lx0 - 1) >> 1;
+        const size_t splane = (size_t)D.H1 * D.P1;
+        const unsigned rowb = (unsigned)D.P1 * 4u;
+        const unsigned o = (unsigned)r0 * rowb + (unsigned)c0 * 4u;      // byte offset inside a plane (planes < 4 GB)
+        f4_t qg[3], qr[3], ng[3], nr[3];
+        {
+            const char *gb = (const char *)(arena + D.g1), *rb = (const char *)(arena + D.r1);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                qg[r] = ld_f4_a4((const float *)(gb + (o + r * rowb)));
+                qr[r] = ld_f4_a4((const float *)(rb + (o + r * rowb)));
+            }
+        }
 #pragma unroll
         for (int c = 0; c < CN; ++c) {
+            if (c + 1 < CN) {
+                const char *gb = (const char *)(arena + D.g1 + (c + 1) * splane);
+                const char *rb = (const char *)(arena + D.r1 + (c + 1) * splane);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    ng[r] = ld_f4_a4((const float *)(gb + (o + r * rowb)));
+                    nr[r] = ld_f4_a4((const float *)(rb + (o + r * rowb)));
+                }
+            }
             float ug[2][4], ur[2][4];
-            up_regs<XO, YO>(qg[c], ug);
-            up_regs<XO, YO>(qr[c], ur);
+            up_regs<XO, YO>(qg, ug);
+            up_regs<XO, YO>(qr, ur);
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -932,6 +938,10 @@ __device__ __forceinline__ void gather_tile_fast(const FinalDesc &D, const float
                     const float wl = lap * w0[j][k];
                     acc[j][k][c] += ur[j][k] + wl;
                 }
+            if (c + 1 < CN) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) { qg[r] = ng[r]; qr[r] = nr[r]; }
+            }
         }
     } else {
 #pragma unroll
