@@ -257,6 +257,39 @@ def test_full_size_200mp_properties():
     pipe.close()
 
 
+@pytest.mark.parametrize("workload,world", [("100MP", 2), ("150MP", 4), ("200MP-kd", 8)])
+def test_baseline_configs_strip_consistency(workload, world):
+    """BASELINE configs 2 (100 MP, 3x3), 4 (150 MP, 4x4) and 5 (200 MP non-uniform) at full size: every rank of a strip
+    partition, rehearsed with only the rows its exchange plan delivers, reproduces its rows of the monolithic canvas
+    bit for bit, and the metric partial sums add up (SSE exactly)."""
+    import torch
+    import device_pipeline as dp
+    geo = dp.workload_geometry(workload)
+    H, W = geo.canvas_h, geo.canvas_w
+    mono = dp.DevicePipeline(geo, 0, 1, 0)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    small = torch.randint(0, 256, (H // 12 + 2, (W // 12 + 2) * 3), dtype=torch.uint8, device="cuda", generator=g)
+    image = torch.empty((H, W * 3), dtype=torch.uint8, device="cuda")
+    mono.ctx.resize_cubic_u8(small.data_ptr(), small.stride(0), small.shape[0], small.shape[1] // 3, 3, image.data_ptr(), W * 3, H, W)
+    reference = torch.roll(image, shifts=3, dims=1)
+    mono.step(image, reference)
+    torch.cuda.synchronize()
+    full_tiles = {t: mono.local_tiles[t] for t in range(len(geo.rects))}
+    sums = torch.zeros_like(mono.results)
+    for r in range(world):
+        p = dp.DevicePipeline(geo, r, world, 0)
+        p.rehearse_fill(full_tiles)
+        p.rehearse_step(reference, staged=(r % 2 == 0))
+        torch.cuda.synchronize()
+        a, b = p.strip
+        assert torch.equal(p.canvas[a:b], mono.canvas[a:b]), (workload, r)
+        sums += p.results
+        p.close()
+    assert float(sums[0]) == float(mono.results[0])
+    assert torch.allclose(sums[1:], mono.results[1:], rtol=1e-12, atol=0)
+    mono.close()
+
+
 def test_gigapixel_properties():
     """Maximum-size case (0.92 GP canvas, 49 tiles of 6200 x 4400, 1.34 G tile pixels, a 17 GB pyramid arena whose
     float offsets exceed 2^31): (1) the canvas of two strip plans equals the monolithic one bit for bit, (2) the
