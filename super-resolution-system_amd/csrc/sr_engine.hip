@@ -319,6 +319,12 @@ __device__ __forceinline__ f4_t ld_f4_a4(const float *p) { return *(const f4_a4_
 __device__ __forceinline__ f4_t ld_f4(const float *p) { return *(const f4_t *)p; }
 __device__ __forceinline__ void st_f4(float *p, f4_t v) { *(f4_t *)p = v; }
 __device__ __forceinline__ u3_t ld_u3_a1(const void *p) { return *(const u3_a1_t *)p; }
+// Same through a global-address-space pointer: for addresses that come out of a descriptor table in memory (tile
+// pointers), where the compiler would otherwise emit flat_load (both wait counters, aperture check).
+__device__ __forceinline__ u3_t ld_u3_a1_g(const void *p)
+{
+    return *(const __attribute__((address_space(1))) u3_a1_t *)p;
+}
 
 // One output pixel (all planes) of level lvl+1 from level lvl -- the generic form with every border rule.
 template <int SRC>
@@ -408,6 +414,14 @@ __host__ __device__ __forceinline__ int down_ncg(int ws, int wo)
     return a < b ? a : b;
 }
 
+// REFLECT_101 of a row index that leaves [0, n) by at most n - 1 (one bounce, no loop) -- the march's rows do by <= 2
+__device__ __forceinline__ int reflect101_once(int p, int n)
+{
+    if (n == 1) return 0;
+    p = p < 0 ? -p : p;
+    return p >= n ? 2 * n - 2 - p : p;
+}
+
 // horizontal pass of one u8 row for the thread's 4 outputs x CN channels.  All values are integers below 2^24, so
 // fp32 evaluates them exactly in any order: bit-identical to ((s2*6 + (s1+s3)*4) + s0) + s4 with two fmas.
 template <int CN>
@@ -427,13 +441,14 @@ template <int CN>
 __device__ __forceinline__ void down_load_u8(const unsigned char *__restrict__ base, long long stride, int row, int xb,
                                              unsigned (&wds)[(CN == 3) ? 9 : 3])
 {
+    // the tile pointer comes out of a table in memory: tell the compiler it is global memory (global_load, not flat_load)
     const unsigned char *p = base + (size_t)row * stride + (size_t)xb * CN;
     if (CN == 3) {
-        const u3_t q0 = ld_u3_a1(p), q1 = ld_u3_a1(p + 12), q2 = ld_u3_a1(p + 24);
+        const u3_t q0 = ld_u3_a1_g(p), q1 = ld_u3_a1_g(p + 12), q2 = ld_u3_a1_g(p + 24);
         wds[0] = q0.x; wds[1] = q0.y; wds[2] = q0.z; wds[3] = q1.x; wds[4] = q1.y; wds[5] = q1.z;
         wds[6] = q2.x; wds[7] = q2.y; wds[8] = q2.z;
     } else {
-        const u3_t q0 = ld_u3_a1(p);
+        const u3_t q0 = ld_u3_a1_g(p);
         wds[0] = q0.x; wds[1] = q0.y; wds[2] = q0.z;
     }
 }
@@ -493,23 +508,28 @@ __global__ __launch_bounds__(256) void k_down_march(const TileDev *__restrict__ 
         constexpr int NW = (CN == 3) ? 9 : 3, NV = 4 * CN;
         const TileSrc S = srcs[blockIdx.z];
         const unsigned char *base = (const unsigned char *)S.p;
-        unsigned w0[NW], w1[NW];
+        unsigned w0[NW], w1[NW], n0[NW], n1[NW];
         float e0[NV], o0[NV], e1[NV], o1[NV], e2[NV];
-        down_load_u8<CN>(base, S.stride, reflect101(2 * y_begin - 2, hs), xb, w0);
+        down_load_u8<CN>(base, S.stride, reflect101_once(2 * y_begin - 2, hs), xb, w0);
+        down_load_u8<CN>(base, S.stride, reflect101_once(2 * y_begin - 1, hs), xb, w1);
+        down_load_u8<CN>(base, S.stride, 2 * y_begin, xb, n0);
         down_row_u8<CN>(w0, e0);
-        down_load_u8<CN>(base, S.stride, reflect101(2 * y_begin - 1, hs), xb, w0);
-        down_row_u8<CN>(w0, o0);
-        down_load_u8<CN>(base, S.stride, 2 * y_begin, xb, w0);
-        down_row_u8<CN>(w0, e1);
-        down_load_u8<CN>(base, S.stride, reflect101(2 * y_begin + 1, hs), xb, w0);
-        down_load_u8<CN>(base, S.stride, reflect101(2 * y_begin + 2, hs), xb, w1);
+        down_row_u8<CN>(w1, o0);
+        down_row_u8<CN>(n0, e1);
+        down_load_u8<CN>(base, S.stride, reflect101_once(2 * y_begin + 1, hs), xb, w0);
+        down_load_u8<CN>(base, S.stride, reflect101_once(2 * y_begin + 2, hs), xb, w1);
         for (int y = y_begin; y < y_end; ++y) {
+            // the two rows of the NEXT output row are requested first and land in their own registers: a whole
+            // iteration of arithmetic (row passes of the current rows, column pass, stores) covers their latency
+            // (unconditional -- the last iteration re-reads its own rows -- so the compiler can keep exactly these
+            // loads outstanding with a counted s_waitcnt instead of draining at a control-flow join)
+            const int yn = min(y + 1, y_end - 1);
+            down_load_u8<CN>(base, S.stride, reflect101_once(2 * yn + 1, hs), xb, n0);
+            down_load_u8<CN>(base, S.stride, reflect101_once(2 * yn + 2, hs), xb, n1);
             down_row_u8<CN>(w0, o1);
             down_row_u8<CN>(w1, e2);
-            if (y + 1 < y_end) {        // rows of the next output row: in flight during the arithmetic below
-                down_load_u8<CN>(base, S.stride, reflect101(2 * y + 3, hs), xb, w0);
-                down_load_u8<CN>(base, S.stride, reflect101(2 * y + 4, hs), xb, w1);
-            }
+#pragma unroll
+            for (int i = 0; i < NW; ++i) { w0[i] = n0[i]; w1[i] = n1[i]; }
 #pragma unroll
             for (int c = 0; c < CN; ++c) {
                 f4_t ov;
@@ -531,23 +551,24 @@ __global__ __launch_bounds__(256) void k_down_march(const TileDev *__restrict__ 
 #pragma unroll 1
         for (int c = 0; c < CN; ++c) {
             const float *plane = arena + T.g_off[lvl] + c * splane;
-            float s0[11], s1[11];
+            float s0[11], s1[11], t0[11], t1[11];
             float e0[4], o0[4], e1[4], o1[4], e2[4];
-            down_load_f32(plane, ps, reflect101(2 * y_begin - 2, hs), xb, s0);
+            down_load_f32(plane, ps, reflect101_once(2 * y_begin - 2, hs), xb, s0);
+            down_load_f32(plane, ps, reflect101_once(2 * y_begin - 1, hs), xb, s1);
+            down_load_f32(plane, ps, 2 * y_begin, xb, t0);
             down_row_f32(s0, e0);
-            down_load_f32(plane, ps, reflect101(2 * y_begin - 1, hs), xb, s0);
-            down_row_f32(s0, o0);
-            down_load_f32(plane, ps, 2 * y_begin, xb, s0);
-            down_row_f32(s0, e1);
-            down_load_f32(plane, ps, reflect101(2 * y_begin + 1, hs), xb, s0);
-            down_load_f32(plane, ps, reflect101(2 * y_begin + 2, hs), xb, s1);
+            down_row_f32(s1, o0);
+            down_row_f32(t0, e1);
+            down_load_f32(plane, ps, reflect101_once(2 * y_begin + 1, hs), xb, s0);
+            down_load_f32(plane, ps, reflect101_once(2 * y_begin + 2, hs), xb, s1);
             for (int y = y_begin; y < y_end; ++y) {
+                const int yn = min(y + 1, y_end - 1);   // next output row's rows first, into their own registers
+                down_load_f32(plane, ps, reflect101_once(2 * yn + 1, hs), xb, t0);
+                down_load_f32(plane, ps, reflect101_once(2 * yn + 2, hs), xb, t1);
                 down_row_f32(s0, o1);
                 down_row_f32(s1, e2);
-                if (y + 1 < y_end) {
-                    down_load_f32(plane, ps, reflect101(2 * y + 3, hs), xb, s0);
-                    down_load_f32(plane, ps, reflect101(2 * y + 4, hs), xb, s1);
-                }
+#pragma unroll
+                for (int i = 0; i < 11; ++i) { s0[i] = t0[i]; s1[i] = t1[i]; }
                 f4_t ov;
                 float o[4];
 #pragma unroll
@@ -879,7 +900,7 @@ __device__ __forceinline__ void gather_tile_fast(const FinalDesc &D, const float
     for (int j = 0; j < 2; ++j) {
         const char *srow = (const char *)D.src + (size_t)(ly0 + j) * D.stride;
         if (DT == SRC_U8 && CN == 3) {
-            qs[j] = ld_u3_a1(srow + (size_t)lx0 * 3);
+            qs[j] = ld_u3_a1_g(srow + (size_t)lx0 * 3);
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -1347,8 +1368,8 @@ __global__ __launch_bounds__(256) void k_tile_extract(const unsigned char *__res
         // unaligned access; a dword-aligned destination row gets the aligned store
         const unsigned char *sp = img + (size_t)(D.y + r) * istride + (size_t)D.x * cn + b0;
         const u4_t v = *(const u4_a1_t *)sp;
-        if (((((size_t)D.dst) | (size_t)D.dstride) & 3) == 0) *(u4_a4_t *)d = v;
-        else *(u4_a1_t *)d = v;
+        if (((((size_t)D.dst) | (size_t)D.dstride) & 3) == 0) *(__attribute__((address_space(1))) u4_a4_t *)d = v;
+        else *(__attribute__((address_space(1))) u4_a1_t *)d = v;
         return;
     }
     const int nb = (int)min((long long)16, row_bytes - b0);
