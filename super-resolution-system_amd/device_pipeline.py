@@ -328,15 +328,22 @@ class DevicePipeline:
                     ptrs.append(local[t].data_ptr())
                 else:
                     ptrs.append(recv[t].data_ptr() - a * self._strides[t])   # virtual row 0
-            self.sets.append(dict(local=local, recv=recv, ptrs=ptrs,
-                                  results=torch.zeros(4, dtype=torch.float64, device=self.dev)))
-        self.canvas = torch.zeros((geo.canvas_h, geo.canvas_w * cn), **u8)
+            self.sets.append(dict(local=local, recv=recv, ptrs=ptrs))
+        # Canvas and metric sums are double-buffered too: in a stream of images the (VALU-bound) assessment of image
+        # i runs on a second HIP stream beside the (bandwidth-bound) tile stage and pyramids of image i+1.
+        self.canvases = [torch.zeros((geo.canvas_h, geo.canvas_w * cn), **u8) for _ in range(2)]
+        self.results_bufs = [torch.zeros(4, dtype=torch.float64, device=self.dev) for _ in range(2)]   # sr_assess_sums
+        self.main_stream = torch.cuda.current_stream(self.dev)
+        self.qa_stream = torch.cuda.Stream(self.dev)
+        self.qa_ctx = _native.Context(self.device, stream=self.qa_stream.cuda_stream)
+        self._e_qa = [None, None]         # assessment of the image in canvas slot j has finished
+        self._slot = 0                    # canvas / result slot of the image in progress
         self.plan = _native.BlendPlan(self.ctx, geo.rects, cn, geo.canvas_h, geo.canvas_w, geo.levels,
                                       geo.weight_type, self.row_begin, self.row_end)
         self._cur = 0                 # buffer set of the step in progress
         self._pending = None          # exchange work handles of the set in progress (pipeline_*)
-        self._reduce_work = []
-        self._done = 0                # buffer set holding the last finished step's sums
+        self._reduce_work = [[], []]
+        self._done = 0                # canvas / result slot of the last finished image
         self._first = True
 
     # set 0 under the names the single-step path and the tests use
@@ -350,7 +357,11 @@ class DevicePipeline:
 
     @property
     def results(self):
-        return self.sets[self._done]["results"]
+        return self.results_bufs[self._done]
+
+    @property
+    def canvas(self):
+        return self.canvases[self._done]
 
     @property
     def _ptrs(self):
@@ -373,38 +384,40 @@ class DevicePipeline:
             return []
         return exchange_tile_rows(self.xplan, self.rank, self.sets[k]["local"], self.sets[k]["recv"], self.group)
 
-    def stage_blend(self, pending=(), k: int = 0):
+    def stage_blend(self, pending=(), k: int = 0, slot: int = 0):
         """Pyramids of the tiles this rank already holds run while the exchange is in flight; the tiles that
         arrive are processed after the wait, then the canvas gather over all of them."""
-        ptrs = self.sets[k]["ptrs"]
+        ptrs, canvas = self.sets[k]["ptrs"], self.canvases[slot]
         if not pending:
-            self.plan.blend(ptrs, self._strides, self.canvas.data_ptr(), self.canvas.stride(0))
+            self.plan.blend(ptrs, self._strides, canvas.data_ptr(), canvas.stride(0))
             return
         self.plan.pyramids(ptrs, self._strides, self._local_needed, first=True)
         for w in pending:
             w.wait()
         self.plan.pyramids(ptrs, self._strides, self._remote_needed, first=False)
-        self.plan.gather(ptrs, self._strides, self.canvas.data_ptr(), self.canvas.stride(0))
+        self.plan.gather(ptrs, self._strides, canvas.data_ptr(), canvas.stride(0))
 
-    def stage_assess(self, reference, k: int = 0):
+    def stage_assess(self, reference, slot: int = 0, ctx=None):
         """PSNR (exact integer SSE) and the three SSIM variants over this rank's strip, as partial sums left on
-        the device: one fused pass over both images -- sr_assess_u8_async."""
+        the device: one fused pass over both images -- sr_assess_u8_async (on ``ctx``'s stream)."""
         g = self.geo
+        ctx = self.ctx if ctx is None else ctx
+        canvas = self.canvases[slot]
         s0, s1 = self.strip
         flags = _native.ASSESS_SSE
         for mode, bit in (("uniform", _native.ASSESS_UNIFORM7), ("gauss", _native.ASSESS_GAUSS11),
                           ("simple", _native.ASSESS_SIMPLE)):
             if mode in self.ssim_modes:
                 flags |= bit
-        self.ctx.assess_u8_async(reference.data_ptr(), reference.stride(0), self.canvas.data_ptr(),
-                                 self.canvas.stride(0), g.canvas_h, g.canvas_w, g.cn,
-                                 self.sets[k]["results"].data_ptr(), flags=flags, row_begin=s0, row_end=s1)
+        ctx.assess_u8_async(reference.data_ptr(), reference.stride(0), canvas.data_ptr(), canvas.stride(0),
+                            g.canvas_h, g.canvas_w, g.cn, self.results_bufs[slot].data_ptr(), flags=flags,
+                            row_begin=s0, row_end=s1)
 
-    def stage_reduce(self, k: int = 0, async_op: bool = False):
+    def stage_reduce(self, slot: int = 0, async_op: bool = False):
         if self.world == 1:
             return None
         import torch.distributed as dist
-        res = self.sets[k]["results"]
+        res = self.results_bufs[slot]
         if dist.get_backend(self.group) == "gloo":          # rehearsal backend: reduce on the host
             host = res.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
@@ -414,6 +427,7 @@ class DevicePipeline:
 
     def step(self, image, reference):
         """One image, start to finish (buffer set 0)."""
+        self.pipeline_finish()                            # a stream in progress writes the same buffers
         self.stage_tile(image)
         pending = self.stage_exchange()
         self.stage_blend(pending)
@@ -421,7 +435,12 @@ class DevicePipeline:
         self.stage_reduce()
         self._done = 0
 
-    # -- a stream of images: the exchange of image i+1 overlaps the blend / assessment of image i -----------------
+    # -- a stream of images --------------------------------------------------------------------------------------
+    # Two overlaps, both across images, every image still gets every stage:
+    #   * the exchange of image i+1 runs under the blend of image i (double-buffered tile / receive sets),
+    #   * the assessment of image i runs on a second HIP stream under the tile stage and pyramids of image i+1
+    #     (double-buffered canvas and sums): the assessment is fp64-VALU-bound and leaves HBM idle, the pyramids are
+    #     bandwidth-bound and leave the VALUs idle.
     def pipeline_begin(self, image):
         """Tile stage + posted exchange of the first image of a stream."""
         self._cur = 0
@@ -430,11 +449,12 @@ class DevicePipeline:
         self._pending = self.stage_exchange(0)
 
     def pipeline_step(self, reference, next_image=None):
-        """Finishes the image in flight; when ``next_image`` is given its tile stage and exchange are started as soon
-        as this image's rows have arrived, into the other buffer set, so the transfer runs under the remaining
-        pyramids, the canvas gather and the assessment of this image.  Every image still gets every stage; only the
-        order across images changes.  One exchange batch is in flight at any time."""
-        k = self._cur
+        """Finishes the image in flight.  When ``next_image`` is given its tile stage and exchange are started as soon
+        as this image's rows have arrived, into the other buffer set.  The assessment is queued on the second stream
+        behind this image's gather; the metric all-reduce follows it there.  One exchange batch is in flight at any
+        time."""
+        torch = self.torch
+        k, j = self._cur, self._slot
         ptrs, pending = self.sets[k]["ptrs"], self._pending
         # Only the first image of a stream has its exchange still in flight when its blend starts (worth splitting the
         # pyramids into held / arriving tiles); later images' rows were moved under the previous image's work, so
@@ -450,31 +470,43 @@ class DevicePipeline:
         if overlap:                                       # start image i+1 before the rest of image i
             self.stage_tile(next_image, nk)
             self._pending = self.stage_exchange(nk)
-        self._finish_blend(k, staged)
-        self.stage_assess(reference, k)
-        for w in self._reduce_work:                       # the previous image's sums (other buffer set)
-            w.wait()
-        w = self.stage_reduce(k, async_op=True)
-        self._reduce_work = [w] if w is not None else []
-        if next_image is not None and not overlap:        # one buffer set (single GPU): plain order
+        if self._e_qa[j] is not None:                     # canvas slot j: its previous image has been assessed
+            self.main_stream.wait_event(self._e_qa[j])
+        self._finish_blend(k, staged, j)
+        blended = torch.cuda.Event()
+        blended.record(self.main_stream)
+        with torch.cuda.stream(self.qa_stream):
+            self.qa_stream.wait_event(blended)
+            for w in self._reduce_work[j]:                # the sums of slot j two images ago have been reduced
+                w.wait()
+            self.stage_assess(reference, j, self.qa_ctx)
+            w = self.stage_reduce(j, async_op=True)
+            self._reduce_work[j] = [w] if w is not None else []
+            self._e_qa[j] = torch.cuda.Event()
+            self._e_qa[j].record(self.qa_stream)
+        if next_image is not None and not overlap:        # one buffer set (single GPU): next tile stage in plain order
             self.stage_tile(next_image, nk)
             self._pending = self.stage_exchange(nk)
         elif next_image is None:
             self._pending = None
-        self._done, self._cur = k, nk
+        self._done, self._cur, self._slot = j, nk, 1 - j
 
-    def _finish_blend(self, k, staged):
-        ptrs = self.sets[k]["ptrs"]
+    def _finish_blend(self, k, staged, slot=0):
+        ptrs, canvas = self.sets[k]["ptrs"], self.canvases[slot]
         if staged:
             self.plan.pyramids(ptrs, self._strides, self._remote_needed, first=False)
-            self.plan.gather(ptrs, self._strides, self.canvas.data_ptr(), self.canvas.stride(0))
+            self.plan.gather(ptrs, self._strides, canvas.data_ptr(), canvas.stride(0))
         else:
-            self.plan.blend(ptrs, self._strides, self.canvas.data_ptr(), self.canvas.stride(0))
+            self.plan.blend(ptrs, self._strides, canvas.data_ptr(), canvas.stride(0))
 
     def pipeline_finish(self):
-        for w in self._reduce_work:
-            w.wait()
-        self._reduce_work = []
+        """Joins the second stream: after this the main stream (and a device synchronise) see every image's sums."""
+        for j in (0, 1):
+            for w in self._reduce_work[j]:
+                w.wait()
+            self._reduce_work[j] = []
+            if self._e_qa[j] is not None:
+                self.main_stream.wait_event(self._e_qa[j])
 
     # -- single-process rehearsal of a rank (tests): same buffers, same staged kernels, no communicator ------------
     def rehearse_fill(self, full_tiles: Dict[int, "object"]):
@@ -491,9 +523,9 @@ class DevicePipeline:
         if staged:
             self.plan.pyramids(self._ptrs, self._strides, self._local_needed, first=True)
             self.plan.pyramids(self._ptrs, self._strides, self._remote_needed, first=False)
-            self.plan.gather(self._ptrs, self._strides, self.canvas.data_ptr(), self.canvas.stride(0))
+            self.plan.gather(self._ptrs, self._strides, self.canvases[0].data_ptr(), self.canvases[0].stride(0))
         else:
-            self.plan.blend(self._ptrs, self._strides, self.canvas.data_ptr(), self.canvas.stride(0))
+            self.plan.blend(self._ptrs, self._strides, self.canvases[0].data_ptr(), self.canvases[0].stride(0))
         self.stage_assess(reference)
         self._done = 0
 
@@ -501,6 +533,7 @@ class DevicePipeline:
     def metrics(self) -> Dict[str, float]:
         """Whole-image scores from the (all-reduced) partial sums; synchronises."""
         g = self.geo
+        self.torch.cuda.synchronize(self.dev)             # both streams
         vals = self.results.cpu().numpy()
         out = {"psnr": _native.psnr_from_sse(int(round(vals[0])), g.canvas_h * g.canvas_w * g.cn, 255.0)}
         for i, mode in enumerate(("uniform", "gauss", "simple")):
@@ -509,5 +542,7 @@ class DevicePipeline:
         return out
 
     def close(self):
+        self.torch.cuda.synchronize(self.dev)
         self.plan.close()
+        self.qa_ctx.close()
         self.ctx.close()

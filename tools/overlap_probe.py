@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Probe: does running the (VALU-bound) assessment of image i on a second stream beside the (bandwidth-bound) tile stage
+and pyramids of image i+1 raise the single-GPU throughput?  Two contexts on two HIP streams, canvases and result words
+double-buffered, events for the two dependencies.  usage (GPU box): python tools/overlap_probe.py"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "super-resolution-system_amd")):
+    sys.path.insert(0, p)
+import numpy as np            # noqa: E402
+import torch                  # noqa: E402
+import _native                # noqa: E402
+import bench                  # noqa: E402
+import device_pipeline as dp  # noqa: E402
+
+geo = dp.workload_geometry("200MP")
+H, W, cn = geo.canvas_h, geo.canvas_w, 3
+dev = torch.device("cuda", 0)
+PRIO = int(os.environ.get("PROBE_PRIO", "0"))
+s1 = torch.cuda.Stream(dev, priority=-1) if PRIO else torch.cuda.Stream(dev)
+s2 = torch.cuda.Stream(dev)
+with torch.cuda.stream(s1):
+    pipe = dp.DevicePipeline(geo, 0, 1, 0)          # blend context on s1
+qa = _native.Context(0, stream=s2.cuda_stream)       # assessment context on s2
+src = bench.synthetic_source()
+t = torch.from_numpy(src).to(dev)
+image = torch.empty((H, W * cn), dtype=torch.uint8, device=dev)
+pipe.ctx.resize_cubic_u8(t.data_ptr(), src.shape[1] * cn, src.shape[0], src.shape[1], cn, image.data_ptr(), W * cn, H, W)
+torch.cuda.synchronize()
+reference = image.clone()
+canv = [torch.zeros((H, W * cn), dtype=torch.uint8, device=dev) for _ in range(2)]
+res = [torch.zeros(4, dtype=torch.float64, device=dev) for _ in range(2)]
+ptrs, strides = pipe.sets[0]["ptrs"], pipe._strides
+
+
+def run(n, overlap):
+    done = [None, None]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n):
+        k = i & 1
+        with torch.cuda.stream(s1):
+            pipe.stage_tile(image)
+            if done[k] is not None:
+                s1.wait_event(done[k])                     # canvas k is free again
+            pipe.plan.blend(ptrs, strides, canv[k].data_ptr(), canv[k].stride(0))
+            e = torch.cuda.Event()
+            e.record(s1)
+        sq = s2 if overlap else s1
+        ctx = qa if overlap else pipe.ctx
+        with torch.cuda.stream(sq):
+            sq.wait_event(e)
+            ctx.assess_u8_async(reference.data_ptr(), reference.stride(0), canv[k].data_ptr(), canv[k].stride(0), H, W, cn,
+                                res[k].data_ptr())
+            d = torch.cuda.Event()
+            d.record(sq)
+            done[k] = d
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / n
+
+
+run(3, False); run(3, True)
+seq = run(20, False)
+ovl = run(20, True)
+print(json.dumps({"sequential_ms_per_image": round(seq, 4), "two_stream_ms_per_image": round(ovl, 4),
+                  "results_equal": bool(torch.equal(res[0], res[1]))}))
