@@ -21,7 +21,17 @@ H, W, cn = geo.canvas_h, geo.canvas_w, 3
 dev = torch.device("cuda", 0)
 PRIO = int(os.environ.get("PROBE_PRIO", "0"))
 s1 = torch.cuda.Stream(dev, priority=-1) if PRIO else torch.cuda.Stream(dev)
-s2 = torch.cuda.Stream(dev)
+MASK = os.environ.get("PROBE_QA_MASK")               # e.g. 77777777: the assessment stream may use 3 of every 4 CUs
+if MASK:
+    import ctypes
+    hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    raw = ctypes.c_void_p()
+    words = (ctypes.c_uint32 * 8)(*([int(MASK, 16)] * 8))
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(raw), 8, words)
+    assert rc == 0, rc
+    s2 = torch.cuda.ExternalStream(raw.value)
+else:
+    s2 = torch.cuda.Stream(dev)
 with torch.cuda.stream(s1):
     pipe = dp.DevicePipeline(geo, 0, 1, 0)          # blend context on s1
 qa = _native.Context(0, stream=s2.cuda_stream)       # assessment context on s2
