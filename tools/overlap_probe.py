@@ -72,8 +72,54 @@ def run(n, overlap):
     return 1e3 * (time.perf_counter() - t0) / n
 
 
-run(3, False); run(3, True)
+def run_b(n):
+    """Variant B: the tile stage of image i+1 also moves to the second stream (behind the assessment of image i-1),
+    into a second set of tile buffers; the main stream keeps pyramids + gather only."""
+    u8 = dict(dtype=torch.uint8, device=dev)
+    sets = [pipe.sets[0]["local"], {t: torch.empty_like(v) for t, v in pipe.sets[0]["local"].items()}]
+    ptr_sets = [[sets[j][t].data_ptr() for t in range(len(geo.rects))] for j in (0, 1)]
+    owned = list(range(len(geo.rects)))
+
+    def extract(ctx, j):
+        ctx.tile_extract(image.data_ptr(), H, W, cn, image.stride(0), [geo.rects[t] for t in owned],
+                         [sets[j][t].data_ptr() for t in owned], [sets[j][t].stride(0) for t in owned])
+
+    done = [None, None]          # assessment of canvas slot finished
+    tiles_ready = [None, None]   # tile set j extracted
+    blend_done = [None, None]    # blend that read tile set j / wrote canvas j finished
+    with torch.cuda.stream(s2):
+        extract(qa, 0)
+        tiles_ready[0] = torch.cuda.Event(); tiles_ready[0].record(s2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n):
+        k = i & 1
+        with torch.cuda.stream(s1):
+            s1.wait_event(tiles_ready[k])
+            if done[k] is not None:
+                s1.wait_event(done[k])
+            pipe.plan.blend(ptr_sets[k], strides, canv[k].data_ptr(), canv[k].stride(0))
+            e = torch.cuda.Event(); e.record(s1)
+            blend_done[k] = e
+        with torch.cuda.stream(s2):
+            if i + 1 < n:                                  # tile stage of the next image, other buffer set
+                if blend_done[1 - k] is not None:
+                    s2.wait_event(blend_done[1 - k])
+                extract(qa, 1 - k)
+                tiles_ready[1 - k] = torch.cuda.Event(); tiles_ready[1 - k].record(s2)
+            s2.wait_event(e)
+            qa.assess_u8_async(reference.data_ptr(), reference.stride(0), canv[k].data_ptr(), canv[k].stride(0), H, W, cn,
+                               res[k].data_ptr())
+            d = torch.cuda.Event(); d.record(s2)
+            done[k] = d
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / n
+
+
+run(3, False); run(3, True); run_b(3)
+varb = run_b(20)
 seq = run(20, False)
 ovl = run(20, True)
 print(json.dumps({"sequential_ms_per_image": round(seq, 4), "two_stream_ms_per_image": round(ovl, 4),
+                  "two_stream_tiles_on_second_ms_per_image": round(varb, 4),
                   "results_equal": bool(torch.equal(res[0], res[1]))}))
