@@ -116,10 +116,43 @@ def run_b(n):
     return 1e3 * (time.perf_counter() - t0) / n
 
 
+def run_c(n):
+    """Variant C: two blend lanes (own stream, context, plan, arena and tile buffers each) alternate images, so the
+    gather of image i can run beside the tile stage and pyramids of image i+1; assessment on the third stream."""
+    s3 = torch.cuda.Stream(dev)
+    with torch.cuda.stream(s3):
+        pipe2 = dp.DevicePipeline(geo, 0, 1, 0)
+    lanes = [(s1, pipe), (s3, pipe2)]
+    done = [None, None]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n):
+        k = i & 1
+        st, pp = lanes[k]
+        with torch.cuda.stream(st):
+            pp.stage_tile(image)
+            if done[k] is not None:
+                st.wait_event(done[k])
+            pp.plan.blend(pp.sets[0]["ptrs"], pp._strides, canv[k].data_ptr(), canv[k].stride(0))
+            e = torch.cuda.Event(); e.record(st)
+        with torch.cuda.stream(s2):
+            s2.wait_event(e)
+            qa.assess_u8_async(reference.data_ptr(), reference.stride(0), canv[k].data_ptr(), canv[k].stride(0), H, W, cn,
+                               res[k].data_ptr())
+            d = torch.cuda.Event(); d.record(s2)
+            done[k] = d
+    torch.cuda.synchronize()
+    dt = 1e3 * (time.perf_counter() - t0) / n
+    return dt
+
+
 run(3, False); run(3, True); run_b(3)
 varb = run_b(20)
+run_c(4)
+varc = run_c(20)
 seq = run(20, False)
 ovl = run(20, True)
 print(json.dumps({"sequential_ms_per_image": round(seq, 4), "two_stream_ms_per_image": round(ovl, 4),
                   "two_stream_tiles_on_second_ms_per_image": round(varb, 4),
+                  "two_blend_lanes_plus_assessment_stream_ms_per_image": round(varc, 4),
                   "results_equal": bool(torch.equal(res[0], res[1]))}))
