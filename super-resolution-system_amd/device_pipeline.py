@@ -6,7 +6,11 @@ strip owner receives the tile rows (plus pyramid halo) it needs over RCCL / xGMI
 with exactly the kernels of the single-GPU path, so its rows are bit-identical to a 1-GPU run
 (SURVEY.md 8(e)).  Quality metrics are partial sums per strip + one 4-element all-reduce.
 
-torch is used for what it is good at here: device buffers, the current stream and
+A stream of images is pipelined (``pipeline_begin / pipeline_step / pipeline_finish``): the assessment of one image
+runs on a second HIP stream beside the tile stage and pyramids of the next, and with several ranks the row exchange
+of the next image runs under the blend of the current one.  ``step()`` is the one-image-at-a-time form.
+
+torch is used for what it is good at here: device buffers, streams and events and
 torch.distributed (backend "nccl" == RCCL on ROCm; "gloo" for the CPU rehearsal in tests/).
 All arithmetic goes through the C ABI (``_native``).
 """
