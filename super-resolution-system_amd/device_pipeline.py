@@ -347,6 +347,7 @@ class DevicePipeline:
         self._cur = 0                 # buffer set of the step in progress
         self._pending = None          # exchange work handles of the set in progress (pipeline_*)
         self._reduce_work = [[], []]
+        self._deferred = None         # slot whose metric all-reduce is still to be posted
         self._done = 0                # canvas / result slot of the last finished image
         self._first = True
 
@@ -474,6 +475,10 @@ class DevicePipeline:
         if overlap:                                       # start image i+1 before the rest of image i
             self.stage_tile(next_image, nk)
             self._pending = self.stage_exchange(nk)
+        # The previous image's metric all-reduce is posted only now, BEHIND the exchange just posted: collectives of one
+        # communicator run in posting order, and an all-reduce posted right after its assessment would sit in front of
+        # this exchange until that assessment (still running beside this image's blend) has finished.
+        self._post_deferred_reduce()
         if self._e_qa[j] is not None:                     # canvas slot j: its previous image has been assessed
             self.main_stream.wait_event(self._e_qa[j])
         self._finish_blend(k, staged, j)
@@ -484,16 +489,24 @@ class DevicePipeline:
             for w in self._reduce_work[j]:                # the sums of slot j two images ago have been reduced
                 w.wait()
             self.stage_assess(reference, j, self.qa_ctx)
-            w = self.stage_reduce(j, async_op=True)
-            self._reduce_work[j] = [w] if w is not None else []
             self._e_qa[j] = torch.cuda.Event()
             self._e_qa[j].record(self.qa_stream)
+        self._deferred = j
         if next_image is not None and not overlap:        # one buffer set (single GPU): next tile stage in plain order
             self.stage_tile(next_image, nk)
             self._pending = self.stage_exchange(nk)
         elif next_image is None:
             self._pending = None
         self._done, self._cur, self._slot = j, nk, 1 - j
+
+    def _post_deferred_reduce(self):
+        j = self._deferred
+        if j is None:
+            return
+        self._deferred = None
+        with self.torch.cuda.stream(self.qa_stream):      # ordered behind the assessment that produced the sums
+            w = self.stage_reduce(j, async_op=True)
+        self._reduce_work[j] = [w] if w is not None else []
 
     def _finish_blend(self, k, staged, slot=0):
         ptrs, canvas = self.sets[k]["ptrs"], self.canvases[slot]
@@ -505,6 +518,7 @@ class DevicePipeline:
 
     def pipeline_finish(self):
         """Joins the second stream: after this the main stream (and a device synchronise) see every image's sums."""
+        self._post_deferred_reduce()
         for j in (0, 1):
             for w in self._reduce_work[j]:
                 w.wait()
