@@ -2080,61 +2080,128 @@ __global__ __launch_bounds__(256) void k_feather_merge(const MergeDev *__restric
                                                        unsigned char *__restrict__ canvas, long long cstride, int ch,
                                                        int cw)
 {
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= cw || y >= ch) return;
-    float acc[3] = {0.f, 0.f, 0.f};
-    float wacc = 0.f;
-    for (int t = 0; t < n; ++t) {
+    // tiles that touch this 256 x 4 pixel block, in list order (wave 0, ballot-compacted): a canvas pixel is covered by
+    // 1-4 of the n tiles, so the per-pixel loop runs over this short list instead of all of them
+    __shared__ int s_cnt;
+    __shared__ int s_list[64];
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const int bx0 = blockIdx.x * 256, by0 = blockIdx.y * 4;
+    if (tid < 64) {
+        int cnt = 0;
+        for (int base = 0; base < n; base += 64) {
+            const int t = base + tid;
+            bool hit = false;
+            if (t < n) {
+                const MergeDev &T = tiles[t];
+                hit = T.x < bx0 + 256 && T.x + T.out_w > bx0 && T.y < by0 + 4 && T.y + T.out_h > by0;
+            }
+            const unsigned long long m = __ballot(hit);
+            if (hit) {
+                const int pos = cnt + __popcll(m & ((1ull << tid) - 1ull));
+                if (pos < 64) s_list[pos] = t;
+            }
+            cnt += __popcll(m);
+        }
+        if (tid == 0) s_cnt = cnt;
+    }
+    __syncthreads();
+    const int ncand = s_cnt;
+    const bool listed = ncand <= 64;                 // more than 64 tiles over one block: walk all of them
+    // one thread = 4 consecutive canvas pixels of one row: the row part of the weight is formed once, unresized tile
+    // pixels come in one 12-byte load
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y;
+    if (x0 >= cw || y >= ch) return;
+    const int nx = min(4, cw - x0);
+    float acc[4][3], wacc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        wacc[k] = 0.f;
+        acc[k][0] = acc[k][1] = acc[k][2] = 0.f;
+    }
+    for (int i = 0; i < (listed ? ncand : n); ++i) {
+        const int t = listed ? s_list[i] : i;
         const MergeDev &T = tiles[t];
-        const int lx = x - T.x, ly = y - T.y;
-        if (lx < 0 || ly < 0 || lx >= T.out_w || ly >= T.out_h) continue;
-        float w = 1.0f;
+        const int lx0 = x0 - T.x, ly = y - T.y;
+        if (lx0 + nx <= 0 || ly < 0 || lx0 >= T.out_w || ly >= T.out_h) continue;
+        // weight[:t] *= linspace(0,1,t); weight[-b:] *= linspace(1,0,b); then columns -- each product in float64,
+        // rounded to fp32 (NumPy's in-place multiply of an fp32 array by an fp64 ramp).  Rows first: shared by the 4 px.
+        float wy = 1.0f;
         if (blending) {
-            // weight[:t] *= linspace(0,1,t); weight[-b:] *= linspace(1,0,b); then columns -- each product in
-            // float64, rounded to fp32 (NumPy's in-place multiply of an fp32 array by an fp64 ramp)
             if (T.ov_t > 0 && ly < T.ov_t) {
                 const double r = (ly == T.ov_t - 1 && T.ov_t > 1) ? 1.0 : (double)ly * T.st + 0.0;
-                w = (float)((double)w * r);
+                wy = (float)((double)wy * r);
             }
             if (T.ov_b > 0 && ly >= T.out_h - T.ov_b) {
-                const int i = ly - (T.out_h - T.ov_b);
-                const double r = (i == T.ov_b - 1 && T.ov_b > 1) ? 0.0 : (double)i * T.sb + 1.0;
-                w = (float)((double)w * r);
-            }
-            if (T.ov_l > 0 && lx < T.ov_l) {
-                const double r = (lx == T.ov_l - 1 && T.ov_l > 1) ? 1.0 : (double)lx * T.sl + 0.0;
-                w = (float)((double)w * r);
-            }
-            if (T.ov_r > 0 && lx >= T.out_w - T.ov_r) {
-                const int i = lx - (T.out_w - T.ov_r);
-                const double r = (i == T.ov_r - 1 && T.ov_r > 1) ? 0.0 : (double)i * T.sr + 1.0;
-                w = (float)((double)w * r);
+                const int j = ly - (T.out_h - T.ov_b);
+                const double r = (j == T.ov_b - 1 && T.ov_b > 1) ? 0.0 : (double)j * T.sb + 1.0;
+                wy = (float)((double)wy * r);
             }
         }
         const unsigned char *base = (const unsigned char *)srcs[t].p;
         const long long st = srcs[t].stride;
-        if (T.resize) {
-            const LinTab X = tabs[T.xtab + lx], Y = tabs[T.ytab + ly];
-            const int x1 = min(X.ofs + 1, T.src_w - 1), y1 = min(Y.ofs + 1, T.src_h - 1);
-            const unsigned char *r0 = base + (size_t)Y.ofs * st, *r1 = base + (size_t)y1 * st;
+        const bool whole = lx0 >= 0 && lx0 + 3 < T.out_w && nx == 4;
+        unsigned pix[12];
+        if (!T.resize && whole) {
+            const u3_t q = ld_u3_a1_g(base + (size_t)ly * st + (size_t)lx0 * 3);
+            const unsigned wd[3] = {q.x, q.y, q.z};
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int s0 = (int)r0[X.ofs * 3 + c] * X.a0 + (int)r0[x1 * 3 + c] * X.a1;
-                const int s1 = (int)r1[X.ofs * 3 + c] * X.a0 + (int)r1[x1 * 3 + c] * X.a1;
-                const int v = (((Y.a0 * (s0 >> 4)) >> 16) + ((Y.a1 * (s1 >> 4)) >> 16) + 2) >> 2;
-                acc[c] += (float)(unsigned char)v * w;
-            }
-        } else {
-            const unsigned char *r0 = base + (size_t)ly * st + (size_t)lx * 3;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) acc[c] += (float)r0[c] * w;
+            for (int b = 0; b < 12; ++b) pix[b] = (wd[b >> 2] >> (8 * (b & 3))) & 0xFFu;
         }
-        wacc += w;
-    }
-    const float wv = wacc > 1e-6f ? wacc : 1e-6f;
-    unsigned char *o = canvas + (size_t)y * cstride + (size_t)x * 3;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) o[c] = (unsigned char)(int)(acc[c] / wv);   // astype(uint8): truncation, no clip
+        for (int k = 0; k < 4; ++k) {
+            const int lx = lx0 + k;
+            if (k >= nx || lx < 0 || lx >= T.out_w) continue;
+            float w = wy;
+            if (blending) {
+                if (T.ov_l > 0 && lx < T.ov_l) {
+                    const double r = (lx == T.ov_l - 1 && T.ov_l > 1) ? 1.0 : (double)lx * T.sl + 0.0;
+                    w = (float)((double)w * r);
+                }
+                if (T.ov_r > 0 && lx >= T.out_w - T.ov_r) {
+                    const int j = lx - (T.out_w - T.ov_r);
+                    const double r = (j == T.ov_r - 1 && T.ov_r > 1) ? 0.0 : (double)j * T.sr + 1.0;
+                    w = (float)((double)w * r);
+                }
+            }
+            if (T.resize) {
+                const LinTab X = tabs[T.xtab + lx], Y = tabs[T.ytab + ly];
+                const int x1 = min(X.ofs + 1, T.src_w - 1), y1 = min(Y.ofs + 1, T.src_h - 1);
+                const unsigned char *r0 = base + (size_t)Y.ofs * st, *r1 = base + (size_t)y1 * st;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int s0 = (int)r0[X.ofs * 3 + c] * X.a0 + (int)r0[x1 * 3 + c] * X.a1;
+                    const int s1 = (int)r1[X.ofs * 3 + c] * X.a0 + (int)r1[x1 * 3 + c] * X.a1;
+                    const int v = (((Y.a0 * (s0 >> 4)) >> 16) + ((Y.a1 * (s1 >> 4)) >> 16) + 2) >> 2;
+                    acc[k][c] += (float)(unsigned char)v * w;
+                }
+            } else if (whole) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[k][c] += (float)pix[3 * k + c] * w;
+            } else {
+                const unsigned char *r0 = base + (size_t)ly * st + (size_t)lx * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[k][c] += (float)r0[c] * w;
+            }
+            wacc[k] += w;
+        }
+    }
+    unsigned ob[12];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float wv = wacc[k] > 1e-6f ? wacc[k] : 1e-6f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ob[3 * k + c] = (unsigned)(unsigned char)(int)(acc[k][c] / wv);   // astype(uint8): truncation, no clip
+    }
+    unsigned char *o = canvas + (size_t)y * cstride + (size_t)x0 * 3;
+    if (nx == 4 && ((cstride & 3) == 0) && ((((size_t)canvas) & 3) == 0)) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            ((unsigned *)o)[q] = ob[4 * q] | (ob[4 * q + 1] << 8) | (ob[4 * q + 2] << 16) | (ob[4 * q + 3] << 24);
+    } else {
+        for (int k = 0; k < nx; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[3 * k + c] = (unsigned char)ob[3 * k + c];
+    }
 }
 
 static void linear_table(int n_src, int n_dst, std::vector<LinTab> &tab)
@@ -3188,7 +3255,7 @@ int sr_feather_merge(sr_ctx *ctx, const sr_merge_tile *h_tiles, int n, void *con
     }
     {
         ProfScope ps(ctx, "feather_merge");
-        dim3 grid((canvas_w + 63) / 64, (canvas_h + 3) / 4), block(64, 4);
+        dim3 grid((canvas_w + 255) / 256, (canvas_h + 3) / 4), block(64, 4);
         hipLaunchKernelGGL(k_feather_merge, grid, block, 0, ctx->stream, (const MergeDev *)p0, (const TileSrc *)p1,
                            (const LinTab *)p2, n, blending ? 1 : 0, d_canvas, (long long)canvas_stride, canvas_h, canvas_w);
     }
