@@ -374,7 +374,7 @@ class Context:
         rects = (TileRect * n)(*[TileRect(int(x), int(y), int(w), int(h)) for (x, y, w, h) in rects_xywh])
         ptrs = (C.c_void_p * n)(*[C.c_void_p(p) for p in d_tiles])
         st = (C.c_int64 * n)(*[int(s) for s in strides])
-        cap = 1 << 16
+        cap = 1 << 18                  # records the first pass can return; a fuller scan is repeated once with room
         while True:
             recs = (SeamRecord * cap)()
             cnt = C.c_int(0)
@@ -383,9 +383,10 @@ class Context:
             if cnt.value <= cap:
                 break
             cap = cnt.value
-        out = [(recs[i].tile, recs[i].x, recs[i].y, recs[i].score) for i in range(cnt.value)]
-        out.sort(key=lambda r: (r[0], r[2], r[1]))
-        return out
+        arr = np.frombuffer(recs, dtype=np.dtype([("tile", "<i4"), ("x", "<i4"), ("y", "<i4"), ("pad", "<i4"),
+                                                  ("score", "<f8")]), count=cnt.value)
+        arr = arr[np.lexsort((arr["x"], arr["y"], arr["tile"]))]
+        return list(zip(arr["tile"].tolist(), arr["x"].tolist(), arr["y"].tolist(), arr["score"].tolist()))
 
     def sse_f32(self, d_a: int, stride_a: int, d_b: int, stride_b: int, h: int, rowlen: int) -> float:
         out = C.c_double(0.0)
