@@ -2015,6 +2015,19 @@ __global__ __launch_bounds__(256) void k_resize_cubic(const unsigned char *__res
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= ww || y >= wh) return;
     const CubicTab X = xt[x0 + x], Y = yt[y0 + y];
+    if (cn == 3 || cn == 1) {                    // one 12-byte load per tap row instead of 12 byte loads (cubic_sample)
+        unsigned char *o = dst + (size_t)y * dstride + (size_t)x * cn;
+        if (cn == 3) {
+            int v[3];
+            cubic_sample<3>(src, sstride, h, w, X, Y, v);
+            o[0] = (unsigned char)v[0]; o[1] = (unsigned char)v[1]; o[2] = (unsigned char)v[2];
+        } else {
+            int v[1];
+            cubic_sample<1>(src, sstride, h, w, X, Y, v);
+            o[0] = (unsigned char)v[0];
+        }
+        return;
+    }
     int sx[4], sy[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
