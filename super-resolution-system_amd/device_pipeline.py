@@ -280,7 +280,14 @@ def exchange_tile_rows(plan: ExchangePlan, rank: int, local_tiles: Dict[int, "ob
         ops.append(dist.P2POp(dist.isend, local_tiles[t][a:b], peer, group))
     for (peer, t, a, b) in recvs:
         ops.append(dist.P2POp(dist.irecv, recv_bufs[t], peer, group))
-    return dist.batch_isend_irecv(ops)
+    try:
+        return dist.batch_isend_irecv(ops)
+    except (RuntimeError, ValueError) as exc:          # a backend without grouped point-to-point: same transfers one by one
+        import sys
+        print(f"[device_pipeline] batch_isend_irecv unavailable ({exc}); posting the transfers individually", file=sys.stderr)
+        works = [dist.isend(local_tiles[t][a:b], peer, group=group, tag=t) for (peer, t, a, b) in sends]
+        works += [dist.irecv(recv_bufs[t], peer, group=group, tag=t) for (peer, t, a, b) in recvs]
+        return works
 
 
 # ---------------------------------------------------------------------------------------------
