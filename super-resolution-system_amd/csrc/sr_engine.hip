@@ -2007,6 +2007,35 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const double *__restric
 // cv2.resize INTER_CUBIC, u8
 // ---------------------------------------------------------------------------------------------
 
+// RGB form: one thread = 4 consecutive destination pixels of a row (one row-table entry, 12 bytes stored as 3 dwords)
+__global__ __launch_bounds__(256) void k_resize_cubic_rgb4(const unsigned char *__restrict__ src, long long sstride, int h,
+                                                           int w, const CubicTab *__restrict__ xt,
+                                                           const CubicTab *__restrict__ yt, int x0, int y0, int ww,
+                                                           int wh, unsigned char *__restrict__ dst, long long dstride)
+{
+    const int x = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= ww || y >= wh) return;
+    const CubicTab Y = yt[y0 + y];
+    const int nx = min(4, ww - x);
+    unsigned ob[12];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int v[3] = {0, 0, 0};
+        if (k < nx) cubic_sample<3>(src, sstride, h, w, xt[x0 + x + k], Y, v);
+        ob[3 * k] = (unsigned)v[0]; ob[3 * k + 1] = (unsigned)v[1]; ob[3 * k + 2] = (unsigned)v[2];
+    }
+    unsigned char *o = dst + (size_t)y * dstride + (size_t)x * 3;
+    if (nx == 4 && ((((size_t)o) & 3) == 0)) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            ((unsigned *)o)[q] = ob[4 * q] | (ob[4 * q + 1] << 8) | (ob[4 * q + 2] << 16) | (ob[4 * q + 3] << 24);
+    } else {
+        for (int k = 0; k < nx; ++k) {
+            o[3 * k] = (unsigned char)ob[3 * k]; o[3 * k + 1] = (unsigned char)ob[3 * k + 1]; o[3 * k + 2] = (unsigned char)ob[3 * k + 2];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_resize_cubic(const unsigned char *__restrict__ src, long long sstride,
                                                       int h, int w, int cn, const CubicTab *__restrict__ xt,
                                                       const CubicTab *__restrict__ yt, int x0, int y0, int ww,
@@ -3749,6 +3778,11 @@ int sr_resize_cubic_window_u8(sr_ctx *ctx, const uint8_t *d_src, int64_t src_str
     {
         ProfScope ps(ctx, "resize_cubic");
         dim3 grid((ww + 63) / 64, (wh + 3) / 4), block(64, 4);
+        if (cn == 3) {
+            dim3 grid4((ww + 255) / 256, (wh + 3) / 4);
+            hipLaunchKernelGGL(k_resize_cubic_rgb4, grid4, block, 0, ctx->stream, d_src, (long long)src_stride, h, w,
+                               (const CubicTab *)dx, (const CubicTab *)dy, x0, y0, ww, wh, d_dst, (long long)dst_stride);
+        } else
         hipLaunchKernelGGL(k_resize_cubic, grid, block, 0, ctx->stream, d_src, (long long)src_stride, h, w, cn,
                            (const CubicTab *)dx, (const CubicTab *)dy, x0, y0, ww, wh, d_dst, (long long)dst_stride);
     }
