@@ -86,6 +86,51 @@ def run(cases: int = 200, seed: int = 1) -> int:
             for bf in bufs:
                 bf.free()
             canvas.free()
+    # TilingModule.merge_tiles feather path: random tiles (resized or not), ramps, canvas crops
+    from oracle import oracle_np as onp
+    merges = 0
+    for it in range(max(cases // 3, 10)):
+        n = int(rng.integers(1, 7))
+        Wc, Hc = int(rng.integers(40, 700)), int(rng.integers(30, 500))
+        datas, metas, descs = [], [], []
+        for _ in range(n):
+            ow, oh = int(rng.integers(8, 300)), int(rng.integers(8, 240))
+            if rng.integers(0, 2):
+                sw, sh = ow, oh
+            else:
+                sw, sh = max(2, int(ow * rng.uniform(0.3, 1.6))), max(2, int(oh * rng.uniform(0.3, 1.6)))
+            x, y = int(rng.integers(0, Wc)), int(rng.integers(0, Hc))
+            ov = [int(rng.integers(0, max(1, min(oh, ow) // 2))) if rng.integers(0, 3) else 0 for _ in range(4)]
+            ov[0], ov[1] = min(ov[0], oh), min(ov[1], oh)
+            ov[2], ov[3] = min(ov[2], ow), min(ov[3], ow)
+            datas.append(rng.integers(0, 256, (sh, sw, 3), dtype=np.uint8))
+            metas.append(dict(global_x=x, global_y=y, output_w=ow, output_h=oh, overlap_top=ov[0], overlap_bottom=ov[1],
+                              overlap_left=ov[2], overlap_right=ov[3]))
+            descs.append(dict(x=x, y=y, src_w=sw, src_h=sh, out_w=ow, out_h=oh, ov_t=ov[0], ov_b=ov[1], ov_l=ov[2], ov_r=ov[3]))
+        blending = bool(rng.integers(0, 4) != 0)
+        want = onp.merge_tiles(datas, metas, Wc, Hc, 1.0, blending)
+        got = ctx.feather_merge_np(datas, descs, Wc, Hc, blending)
+        merges += 1
+        if not np.array_equal(got, want):
+            bad += 1
+            d = np.argwhere(got != want)
+            print("MERGE MISMATCH", it, metas, (Hc, Wc), blending, "first diffs", d[:3].tolist(), "count", len(d))
+    # bicubic resize (cv2.INTER_CUBIC semantics), up and down, 1 and 3 channels
+    resizes = 0
+    for it in range(max(cases // 4, 10)):
+        h, w = int(rng.integers(2, 200)), int(rng.integers(2, 260))
+        dh, dw = max(1, int(h * rng.uniform(0.1, 6.0))), max(1, int(w * rng.uniform(0.1, 6.0)))
+        cn = int(rng.choice([1, 3]))
+        a = rng.integers(0, 256, (h, w, 3) if cn == 3 else (h, w), dtype=np.uint8)
+        da = ctx.upload(a)
+        dd = ctx.alloc(dh * dw * cn)
+        ctx.resize_cubic_u8(da.ptr, w * cn, h, w, cn, dd.ptr, dw * cn, dh, dw)
+        got = ctx.download(dd.ptr, (dh, dw, 3) if cn == 3 else (dh, dw), np.uint8)
+        resizes += 1
+        if not np.array_equal(got, oc.resize_cubic_u8(a, dw, dh)):
+            bad += 1
+            print("RESIZE MISMATCH", it, a.shape, (dh, dw))
+        da.free(); dd.free()
     # fused assessment on random shapes
     for it in range(max(cases // 4, 10)):
         h, w = int(rng.integers(7, 400)), int(rng.integers(7, 700))
@@ -107,7 +152,7 @@ def run(cases: int = 200, seed: int = 1) -> int:
             print("ASSESS MISMATCH", it, shape)
         da.free(); db.free()
     print(f"fuzz: {cases} blend cases ({compared} compared, {rejected} rejected by both, {strips} also as strips) + "
-          f"{max(cases // 4, 10)} assessment cases, {bad} mismatches")
+          f"{merges} feather merges + {resizes} resizes + {max(cases // 4, 10)} assessment cases, {bad} mismatches")
     return bad
 
 
