@@ -115,6 +115,46 @@ def run(cases: int = 200, seed: int = 1) -> int:
             bad += 1
             d = np.argwhere(got != want)
             print("MERGE MISMATCH", it, metas, (Hc, Wc), blending, "first diffs", d[:3].tolist(), "count", len(d))
+    # strip partitions: every rank of a random world over a random (grid or k-d) geometry, rehearsed with only the rows
+    # its exchange plan delivers, reproduces its rows of the monolithic canvas and the metric sums add up
+    import torch
+    import device_pipeline as dp
+    worlds = 0
+    for it in range(max(cases // 20, 3)):
+        if rng.integers(0, 2):
+            geo = dp.kd_geometry(int(rng.integers(500, 1500)), int(rng.integers(400, 1200)), leaves=int(rng.integers(3, 14)),
+                                 overlap=float(rng.uniform(0.10, 0.2)), seed=int(rng.integers(0, 1 << 30)))
+        else:
+            tw, th = int(rng.integers(120, 420)), int(rng.integers(100, 380))
+            geo = dp.grid_geometry(tile_w=tw, tile_h=th, rows=int(rng.integers(1, 5)), cols=int(rng.integers(1, 5)),
+                                   ov_x=int(tw * rng.uniform(0.1, 0.3)), ov_y=int(th * rng.uniform(0.1, 0.3)))
+        if geo.canvas_h < 64:
+            continue
+        world = int(rng.integers(2, 9))
+        Hc, Wc = geo.canvas_h, geo.canvas_w
+        image = torch.from_numpy(rng.integers(0, 256, (Hc, Wc * 3), dtype=np.uint8)).cuda()
+        reference = torch.from_numpy(rng.integers(0, 256, (Hc, Wc * 3), dtype=np.uint8)).cuda()
+        mono = dp.DevicePipeline(geo, 0, 1, 0)
+        mono.step(image, reference)
+        torch.cuda.synchronize()
+        full = {t: mono.local_tiles[t] for t in range(len(geo.rects))}
+        sums = torch.zeros_like(mono.results)
+        ok = True
+        for r in range(world):
+            pr = dp.DevicePipeline(geo, r, world, 0)
+            pr.rehearse_fill(full)
+            pr.rehearse_step(reference, staged=bool(rng.integers(0, 2)))
+            torch.cuda.synchronize()
+            a_, b_ = pr.strip
+            ok = ok and torch.equal(pr.canvas[a_:b_], mono.canvas[a_:b_])
+            sums += pr.results
+            pr.close()
+        ok = ok and float(sums[0]) == float(mono.results[0]) and bool(torch.allclose(sums[1:], mono.results[1:], rtol=1e-12, atol=0))
+        worlds += 1
+        if not ok:
+            bad += 1
+            print("WORLD MISMATCH", it, world, (Hc, Wc), geo.rects)
+        mono.close()
     # bicubic resize (cv2.INTER_CUBIC semantics), up and down, 1 and 3 channels
     resizes = 0
     for it in range(max(cases // 4, 10)):
@@ -152,7 +192,7 @@ def run(cases: int = 200, seed: int = 1) -> int:
             print("ASSESS MISMATCH", it, shape)
         da.free(); db.free()
     print(f"fuzz: {cases} blend cases ({compared} compared, {rejected} rejected by both, {strips} also as strips) + "
-          f"{merges} feather merges + {resizes} resizes + {max(cases // 4, 10)} assessment cases, {bad} mismatches")
+          f"{merges} feather merges + {worlds} strip worlds + {resizes} resizes + {max(cases // 4, 10)} assessment cases, {bad} mismatches")
     return bad
 
 
