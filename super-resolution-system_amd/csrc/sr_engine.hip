@@ -67,13 +67,23 @@ struct sr_ctx {
     size_t scratch_bytes = 0;
     // host copies of small tables handed to hipMemcpyAsync; released at the next stream sync
     std::vector<std::vector<char>> pending_host;
+    size_t pending_bytes = 0;
     CachedTable extract_tab;                            // tile-extract descriptors
     CachedTable resize_tab;                             // cubic tables of the resized assessment
+    CachedTable cubic_tab;                              // cubic tables of sr_resize_cubic_u8
 };
 
 // Enqueue a small host->device table upload whose source stays alive until the next sync.
 static hipError_t upload_small(sr_ctx *c, void *d_dst, const void *h_src, size_t bytes)
 {
+    // bound what a caller that never synchronises can pile up: drain the stream once 32 MB of table copies are parked
+    c->pending_bytes += bytes;
+    if (c->pending_bytes > ((size_t)32 << 20)) {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return e;
+        c->pending_host.clear();
+        c->pending_bytes = bytes;
+    }
     c->pending_host.emplace_back((const char *)h_src, (const char *)h_src + bytes);
     return hipMemcpyAsync(d_dst, c->pending_host.back().data(), bytes, hipMemcpyHostToDevice, c->stream);
 }
@@ -110,7 +120,10 @@ static hipError_t upload_cached(sr_ctx *c, CachedTable &t, const void *h_src, si
 static hipError_t stream_sync(sr_ctx *c)
 {
     hipError_t e = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess) c->pending_host.clear();
+    if (e == hipSuccess) {
+        c->pending_host.clear();
+        c->pending_bytes = 0;
+    }
     return e;
 }
 
@@ -2380,6 +2393,7 @@ int sr_ctx_destroy(sr_ctx *ctx)
         if (ctx->scratch) (void)hipFree(ctx->scratch);
         if (ctx->extract_tab.d) (void)hipFree(ctx->extract_tab.d);
         if (ctx->resize_tab.d) (void)hipFree(ctx->resize_tab.d);
+        if (ctx->cubic_tab.d) (void)hipFree(ctx->cubic_tab.d);
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;
@@ -3769,12 +3783,9 @@ int sr_resize_cubic_window_u8(sr_ctx *ctx, const uint8_t *d_src, int64_t src_str
     std::vector<CubicTab> xt, yt;
     cubic_table(w, dw, xt);
     cubic_table(h, dh, yt);
-    void *scr = nullptr;
-    int rc = ctx_scratch(ctx, sizeof(CubicTab) * ((size_t)dw + dh), &scr);
-    if (rc) return rc;
-    CubicTab *dx = (CubicTab *)scr, *dy = dx + dw;
-    HIPCHK(upload_small(ctx, dx, xt.data(), sizeof(CubicTab) * dw));
-    HIPCHK(upload_small(ctx, dy, yt.data(), sizeof(CubicTab) * dh));
+    xt.insert(xt.end(), yt.begin(), yt.end());          // both axes in one cached device table (re-used per geometry)
+    HIPCHK(upload_cached(ctx, ctx->cubic_tab, xt.data(), sizeof(CubicTab) * xt.size()));
+    CubicTab *dx = (CubicTab *)ctx->cubic_tab.d, *dy = dx + dw;
     {
         ProfScope ps(ctx, "resize_cubic");
         dim3 grid((ww + 63) / 64, (wh + 3) / 4), block(64, 4);
