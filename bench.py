@@ -34,6 +34,7 @@ for p in (ROOT, PKG):
 
 import numpy as np  # noqa: E402
 
+WORKLOAD_CHOICES = ["4MP", "100MP", "150MP", "200MP", "100MP-kd", "150MP-kd", "200MP-kd"]
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
@@ -127,52 +128,49 @@ def cpu_baseline(seed_img: np.ndarray, geo_full, budget_tiles=(4, 4)) -> dict:
                       f"oracle/sr_oracle.c with OpenMP (restated reference CPU path, cv2/skimage absent)"}
 
 
-def main() -> int:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="200MP",
-                    choices=["4MP", "100MP", "150MP", "200MP", "100MP-kd", "150MP-kd", "200MP-kd"])
-    ap.add_argument("--mode", default="strips", choices=["strips", "batch"],
-                    help="strips: one image over all ranks (strong scaling, the BASELINE metric); "
-                         "batch: one image per rank, no data-path communication (config 4, weak scaling)")
-    ap.add_argument("--no-pcie", action="store_true",
-                    help="skip the host->device (inputs) / device->host (canvas) timing that N=1 runs report beside the resident rate")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-prof", action="store_true", help="skip the per-kernel HIP-event timing")
-    args = ap.parse_args()
+def _launch_ranks(n: int, argv) -> int:
+    """``python bench.py --gpus N`` without a launcher around it: start the N ranks as CHILD processes (one per GPU,
+    env:// rendezvous on 127.0.0.1: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) before anything in this
+    process has touched torch or HIP.  The children write straight to our stdout / stderr (rank 0 prints the JSON
+    line).  Returns the first non-zero child status (the other ranks are then stopped), else 0.  Never exec: a process
+    that has initialised the GPU must not be replaced -- and this one never initialises it."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            try:
+                code = p.wait(timeout=0.2)
+            except subprocess.TimeoutExpired:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in alive:                              # a rank failed: the others would wait on it forever
+                    q.terminate()
+    return rc
 
+
+def run_workload(args, workload: str, steps: int, warmup: int, detailed: bool, dist_state) -> dict:
+    """One measurement of `workload` on the ranks of `dist_state`; returns the result record on rank 0 (None elsewhere)."""
     import torch
     import torch.distributed as dist
-    import _native
     import device_pipeline as dp
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
-            return 2
-    if not torch.cuda.is_available():
-        print("bench.py: no GPU visible -- the HIP path has no CPU fallback", file=sys.stderr)
-        return 2
-    # SR_DIST_BACKEND=gloo is the single-GPU rehearsal of the multi-rank path (ranks share one card, rows staged
-    # through the host); the measured configuration is always RCCL ("nccl"), one rank per GPU.
-    backend = os.environ.get("SR_DIST_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank = local_rank % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-
-    geo = dp.workload_geometry(args.workload)
+    world, rank, local_rank, backend, dev = dist_state
+    geo = dp.workload_geometry(workload)
     H, W, cn = geo.canvas_h, geo.canvas_w, geo.cn
 
     # ---- inputs, resident in HBM before the timed region ----------------------------------------
@@ -183,7 +181,6 @@ def main() -> int:
     src_img = np.clip(src_ref.astype(np.int16) + np.random.default_rng(7).integers(-3, 4, src_ref.shape), 0, 255).astype(np.uint8)
     pipe = dp.DevicePipeline(geo, 0, 1, local_rank) if batch else dp.DevicePipeline(geo, rank, world, local_rank)
     ctx = pipe.ctx
-
 
     class _Prof:
         """sr_prof_* on both contexts of the pipeline (blend on the main stream, assessment on the second one)."""
@@ -210,6 +207,7 @@ def main() -> int:
             return out
 
     prof_ctl = _Prof()
+    no_prof = args.no_prof or not detailed
     t_src = torch.from_numpy(np.stack([src_ref, src_img])).to(dev)
     reference = torch.empty((H, W * cn), dtype=torch.uint8, device=dev)
     image = torch.empty((H, W * cn), dtype=torch.uint8, device=dev)
@@ -245,34 +243,34 @@ def main() -> int:
     # region only the dominant kernel is timed -- that measurement is what `roofline` reports.
     evs = None
     dominant = "assess_all"
-    if not args.no_prof and args.warmup > 0:
+    if not no_prof and warmup > 0:
         prof_ctl.enable(True)
         prof_ctl.reset()
-    run_steps(args.warmup)
+    run_steps(warmup)
     torch.cuda.synchronize()
-    if not args.no_prof and args.warmup > 0:
+    if not no_prof and warmup > 0:
         warm = prof_ctl.get()
         if warm:
             dominant = max(warm.items(), key=lambda kv: kv[1][0])[0]
 
-    if not args.no_prof:
+    if not no_prof:
         prof_ctl.enable(True)
         prof_ctl.select(dominant)
         prof_ctl.reset()
     # per-step device time (events on the stream the kernels run on): median / min beside the mean of the contract
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     evs[0].record()
-    run_steps(args.steps)
+    run_steps(steps)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
-    prof_timed = {} if args.no_prof else prof_ctl.get()          # the dominant kernel, inside the timed region
-    prof, prof_steps = {}, max(1, min(args.steps, 5))
-    if not args.no_prof:
+    step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
+    prof_timed = {} if no_prof else prof_ctl.get()               # the dominant kernel, inside the timed region
+    prof, prof_steps = {}, max(1, min(steps, 5))
+    if not no_prof:
         # every family, in its own pass after the timed region, one image at a time on one stream (step()): standalone
         # kernel durations -- in the timed region the assessment shares the GPU with the next image's pyramids
         prof_ctl.select(None)
@@ -290,7 +288,7 @@ def main() -> int:
     metrics = pipe.metrics()
 
     pcie = None
-    if world == 1 and not args.no_pcie:
+    if world == 1 and detailed and not args.no_pcie:
         # the boundary's host-buffer variant: inputs uploaded, canvas downloaded (pinned host memory); never `value`
         h_in = torch.empty((2, H, W * cn), dtype=torch.uint8).pin_memory()
         h_out = torch.empty((H, W * cn), dtype=torch.uint8).pin_memory()
@@ -306,66 +304,28 @@ def main() -> int:
         pcie = {"h2d_ms": round(1e3 * (tb - ta), 3), "h2d_GB": round(2 * H * W * cn / 1e9, 3),
                 "d2h_ms": round(1e3 * (tc - tb), 3), "d2h_GB": round(H * W * cn / 1e9, 3),
                 "note": "pinned host buffers, one copy engine; add to ms_per_step for the host-buffer boundary"}
+        del h_in, h_out
 
+    out = None
     if rank == 0:
-        ms_per_step = 1e3 * elapsed / args.steps
+        ms_per_step = 1e3 * elapsed / steps
         mp = geo.canvas_pixels / 1e6
         alg = algorithmic_bytes(geo)
-        kernels = {}
-        for name, (ms, launches) in prof.items():
-            nsteps = prof_steps
-            per_step_ms = ms / nsteps
-            b = alg.get(name)
-            share = 1.0 / world if (world > 1 and not batch) else 1.0     # each rank moves ~1/N of the bytes (+ halo)
-            kernels[name] = {"ms_per_step": round(per_step_ms, 4), "launches_per_step": launches / nsteps,
-                             "timed_in": "separate sequential pass (standalone)",
-                             "alg_GB": None if b is None else round(b * share / 1e9, 4),
-                             "GBps": None if b is None or per_step_ms <= 0 else round(b * share / 1e9 / (per_step_ms / 1e3), 1)}
-        roofline = None
-        traffic = measured_traffic() if (world == 1 and args.workload == "200MP") else {}
         images = world if batch else 1
-        cands = [(v["ms_per_step"], k) for k, v in kernels.items() if v["alg_GB"] is not None]
-        if cands:
-            _, dom = max(cands)
-            k = kernels[dom]
-            per_launch_ms = k["ms_per_step"] / max(k["launches_per_step"], 1)
-            achieved = k["alg_GB"] / k["launches_per_step"] / (per_launch_ms / 1e3) if per_launch_ms > 0 else 0.0
-            standalone = {"avg_launch_ms": round(per_launch_ms, 4), "achieved": round(achieved, 1),
-                          "frac": round(achieved / HBM_PEAK_GBS, 4)}
-            if dom in prof_timed and prof_timed[dom][1] > 0:      # the same kernel as it ran inside the timed region
-                t_ms, t_n = prof_timed[dom]
-                per_launch_ms = t_ms / t_n
-                achieved = k["alg_GB"] / k["launches_per_step"] / (per_launch_ms / 1e3) if per_launch_ms > 0 else 0.0
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        "traffic": (traffic[dom] / k["launches_per_step"]) if dom in traffic else None,
-                        "traffic_source": traffic.get("_source"),
-                        "avg_launch_ms": round(per_launch_ms, 4),
-                        "alg_bytes_per_launch": k["alg_GB"] / k["launches_per_step"] * 1e9,
-                        "measured_in": "timed region (this kernel shares the GPU with the next image's tile stage and "
-                                       "pyramids there)" if dom in prof_timed else "separate sequential pass",
-                        "standalone": standalone}
-            if dom == "assess_all":
-                roofline["note"] = ("fp64-VALU-bound: the reference's SSIM is float64; ~126 fp64 ops per pixel put its "
-                                    "floor near 0.65 ms at 200 MP, above its 0.2 ms HBM time")
-        gpu_ms = sum(v["ms_per_step"] for v in kernels.values())
-        blend_ms = sum(v["ms_per_step"] for kk, v in kernels.items()
-                       if kk in ("weight_down", "down_l0", "down_l1p", "up_level", "final_gather"))
-        total_alg = sum(alg[kk] for kk in kernels if kk in alg)
         div = world if (world > 1 and not batch) else 1          # strips: each rank moves ~1/N of the bytes
         blend_alg = sum(alg[kk] for kk in ("down_l0", "down_l1p", "up_level", "final_gather")) / div
         out = {
             "metric": "megapixels/sec tile+blend+QA at 200MP, 1/2/4/8 GPU",
-            "value": round(images * mp / (elapsed / args.steps), 1),
+            "value": round(images * mp / (elapsed / steps), 1),
             "unit": "MP/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
             "scaling": "weak" if batch else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic" if backend == "nccl" else f"synthetic (REHEARSAL backend {backend}: not a measurement)",
-            "config": {"workload": f"720p->{args.workload} {geo.canvas_w}x{geo.canvas_h} canvas, "
+            "config": {"workload": f"720p->{workload} {geo.canvas_w}x{geo.canvas_h} canvas, "
                                    f"{len(geo.rects)} tiles {geo.rects[0][2]}x{geo.rects[0][3]}, {geo.levels}-level "
                                    f"Laplacian blend (cosine weights) + PSNR + SSIM(uniform7,gauss11,simple)",
                        "tile_pixels": geo.tile_pixels, "canvas_pixels": geo.canvas_pixels,
@@ -374,31 +334,146 @@ def main() -> int:
                                  + ("; exchange of image i+1 under the blend of image i" if (world > 1 and not batch) else "")},
             "step_ms": {"median": round(step_ms[len(step_ms) // 2], 4), "min": round(step_ms[0], 4),
                         "max": round(step_ms[-1], 4), "clock": "HIP events on the main stream between consecutive images, rank 0"},
-            "pcie": pcie,
-            "end_to_end": {"sr_stub_ms": round(sr_stub_ms, 3), "ms_per_image_with_stub": round(ms_per_step + sr_stub_ms, 3),
-                           "note": "SR stand-in = cv2.INTER_CUBIC upscale of the 720p source on the GPU (sr_resize_cubic_u8), "
-                                   "outside the timed region and outside the roofline"},
-            "roofline": roofline,
-            "kernels": kernels,
-            "blend": {"ms_per_step": round(blend_ms, 4),
-                      "alg_GB": round(blend_alg / 1e9, 3),
-                      "GBps": None if blend_ms <= 0 else round(blend_alg / 1e9 / (blend_ms / 1e3), 1),
-                      "frac_of_peak": None if blend_ms <= 0 else round(blend_alg / 1e9 / (blend_ms / 1e3) / HBM_PEAK_GBS, 4),
-                      "survey_model_GBps": None if blend_ms <= 0 else round(alg["_survey_blend_model"] / div / 1e9 / (blend_ms / 1e3), 1)},
-            "summary": {"gpu_kernel_ms_per_step": round(gpu_ms, 4), "blend_ms_per_step": round(blend_ms, 4),
-                        "alg_GB_per_step": round(total_alg / 1e9, 3),
-                        "blend_GBps_vs_survey_model": None if blend_ms <= 0 else
-                        round(alg["_survey_blend_model"] / 1e9 / (blend_ms / 1e3), 1),
-                        "whole_step_alg_GBps": None if ms_per_step <= 0 else round(total_alg / 1e9 / (ms_per_step / 1e3), 1)},
             "quality": {k: (v if np.isfinite(v) else str(v)) for k, v in metrics.items()},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            # the k-d workloads time the grid geometry of the same canvas (same pixels, same kernels on the CPU side)
-            out["cpu_baseline"] = cpu_baseline(src_ref, dp.workload_geometry(args.workload.replace("-kd", "")))
-        else:
-            out["cpu_baseline"] = None
-        print(json.dumps(out))
+        if detailed:
+            kernels = {}
+            for name, (ms, launches) in prof.items():
+                nsteps = prof_steps
+                per_step_ms = ms / nsteps
+                b = alg.get(name)
+                share = 1.0 / world if (world > 1 and not batch) else 1.0     # each rank moves ~1/N of the bytes (+ halo)
+                kernels[name] = {"ms_per_step": round(per_step_ms, 4), "launches_per_step": launches / nsteps,
+                                 "timed_in": "separate sequential pass (standalone)",
+                                 "alg_GB": None if b is None else round(b * share / 1e9, 4),
+                                 "GBps": None if b is None or per_step_ms <= 0 else round(b * share / 1e9 / (per_step_ms / 1e3), 1)}
+            roofline = None
+            traffic = measured_traffic() if (world == 1 and workload == "200MP") else {}
+            cands = [(v["ms_per_step"], k) for k, v in kernels.items() if v["alg_GB"] is not None]
+            if cands:
+                _, dom = max(cands)
+                k = kernels[dom]
+                per_launch_ms = k["ms_per_step"] / max(k["launches_per_step"], 1)
+                achieved = k["alg_GB"] / k["launches_per_step"] / (per_launch_ms / 1e3) if per_launch_ms > 0 else 0.0
+                standalone = {"avg_launch_ms": round(per_launch_ms, 4), "achieved": round(achieved, 1),
+                              "frac": round(achieved / HBM_PEAK_GBS, 4)}
+                if dom in prof_timed and prof_timed[dom][1] > 0:      # the same kernel as it ran inside the timed region
+                    t_ms, t_n = prof_timed[dom]
+                    per_launch_ms = t_ms / t_n
+                    achieved = k["alg_GB"] / k["launches_per_step"] / (per_launch_ms / 1e3) if per_launch_ms > 0 else 0.0
+                tr = traffic.get(dom)
+                roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                            "traffic": (tr / k["launches_per_step"]) if tr is not None else None,
+                            "traffic_source": traffic.get("_source"),
+                            "traffic_note": traffic.get("_note"),
+                            "avg_launch_ms": round(per_launch_ms, 4),
+                            "alg_bytes_per_launch": k["alg_GB"] / k["launches_per_step"] * 1e9,
+                            "measured_in": "timed region (this kernel shares the GPU with the next image's tile stage and "
+                                           "pyramids there)" if dom in prof_timed else "separate sequential pass",
+                            "standalone": standalone}
+                if dom == "assess_all":
+                    roofline["note"] = ("fp64-VALU-bound: the reference's SSIM is float64; ~126 fp64 ops per pixel put its "
+                                        "floor near 0.65 ms at 200 MP, above its 0.2 ms HBM time")
+            gpu_ms = sum(v["ms_per_step"] for v in kernels.values())
+            blend_ms = sum(v["ms_per_step"] for kk, v in kernels.items()
+                           if kk in ("weight_down", "down_l0", "down_l1p", "up_level", "final_gather"))
+            total_alg = sum(alg[kk] for kk in kernels if kk in alg)
+            out.update({
+                "pcie": pcie,
+                "end_to_end": {"sr_stub_ms": round(sr_stub_ms, 3), "ms_per_image_with_stub": round(ms_per_step + sr_stub_ms, 3),
+                               "note": "SR stand-in = cv2.INTER_CUBIC upscale of the 720p source on the GPU (sr_resize_cubic_u8), "
+                                       "outside the timed region and outside the roofline"},
+                "roofline": roofline,
+                "kernels": kernels,
+                "blend": {"ms_per_step": round(blend_ms, 4),
+                          "alg_GB": round(blend_alg / 1e9, 3),
+                          "GBps": None if blend_ms <= 0 else round(blend_alg / 1e9 / (blend_ms / 1e3), 1),
+                          "frac_of_peak": None if blend_ms <= 0 else round(blend_alg / 1e9 / (blend_ms / 1e3) / HBM_PEAK_GBS, 4),
+                          "survey_model_GBps": None if blend_ms <= 0 else round(alg["_survey_blend_model"] / div / 1e9 / (blend_ms / 1e3), 1)},
+                "summary": {"gpu_kernel_ms_per_step": round(gpu_ms, 4), "blend_ms_per_step": round(blend_ms, 4),
+                            "alg_GB_per_step": round(total_alg / 1e9, 3),
+                            "blend_GBps_vs_survey_model": None if blend_ms <= 0 else
+                            round(alg["_survey_blend_model"] / 1e9 / (blend_ms / 1e3), 1),
+                            "whole_step_alg_GBps": None if ms_per_step <= 0 else round(total_alg / 1e9 / (ms_per_step / 1e3), 1)},
+            })
+            if world == 1 and not args.no_cpu_baseline:
+                # the k-d workloads time the grid geometry of the same canvas (same pixels, same kernels on the CPU side)
+                out["cpu_baseline"] = cpu_baseline(src_ref, dp.workload_geometry(workload.replace("-kd", "")))
+            else:
+                out["cpu_baseline"] = None
     pipe.close()
+    del pipe, reference, image, t_src
+    torch.cuda.empty_cache()
+    return out
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="200MP", choices=WORKLOAD_CHOICES)
+    ap.add_argument("--mode", default="strips", choices=["strips", "batch"],
+                    help="strips: one image over all ranks (strong scaling, the BASELINE metric); "
+                         "batch: one image per rank, no data-path communication (config 4, weak scaling)")
+    ap.add_argument("--sweep", default="100MP,150MP",
+                    help="comma list of further workloads measured briefly after the main one and reported in the "
+                         "`sweep` object of the same JSON line (north_star: 100 / 150 / 200 MP); '' or 'none' to skip")
+    ap.add_argument("--sweep-steps", type=int, default=8)
+    ap.add_argument("--no-pcie", action="store_true",
+                    help="skip the host->device (inputs) / device->host (canvas) timing that N=1 runs report beside the resident rate")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="skip the per-kernel HIP-event timing")
+    args = ap.parse_args()
+
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        return 2
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return _launch_ranks(args.gpus, sys.argv[1:])       # children only; this process never touches the GPU
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr)
+        return 2
+
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible -- the HIP path has no CPU fallback", file=sys.stderr)
+        return 2
+    # SR_DIST_BACKEND=gloo is the single-GPU rehearsal of the multi-rank path (ranks share one card, rows staged
+    # through the host); the measured configuration is always RCCL ("nccl"), one rank per GPU.
+    backend = os.environ.get("SR_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    state = (world, rank, local_rank, backend, dev)
+
+    out = run_workload(args, args.workload, args.steps, args.warmup, True, state)
+    sweep = [w for w in args.sweep.split(",") if w and w != "none" and w != args.workload]
+    sweep_out = {}
+    for wl in sweep:
+        if wl not in WORKLOAD_CHOICES:
+            print(f"bench.py: unknown sweep workload {wl!r}", file=sys.stderr)
+            return 2
+        r = run_workload(args, wl, max(1, args.sweep_steps), min(args.warmup, 2), False, state)
+        if r is not None:
+            sweep_out[wl] = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "step_ms", "quality")}
+            sweep_out[wl]["workload"] = r["config"]["workload"]
+    if rank == 0:
+        out["sweep"] = sweep_out
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
     return 0

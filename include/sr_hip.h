@@ -57,6 +57,8 @@ typedef struct sr_blend_plan sr_blend_plan;
 
 /* ---- library / context ------------------------------------------------------------- */
 SR_API int sr_version(void);
+/* first 16 hex digits of the sha1 over the sources the library was built from (a stale binary shows here) */
+SR_API const char *sr_source_digest(void);
 SR_API const char *sr_last_error(void);
 SR_API int sr_device_count(int *count);
 SR_API int sr_ctx_create(int device_id, sr_ctx **out);
@@ -150,6 +152,9 @@ SR_API int sr_blend_plan_destroy(sr_blend_plan *plan);
  * The multi-GPU exchange plan is built from this on every rank. */
 SR_API int sr_strip_tile_rows(const sr_tile_rect *h_tiles, int n, int levels, int canvas_h,
                               int row_begin, int row_end, int *h_rows);
+/* Analytic worst case of that back-propagation (host only): a strip reads at most *below input rows before and *above
+ * rows after its own rows of a tile (levels of >= 8 rows; 6 levels: 155 / 125). */
+SR_API int sr_pyramid_halo(int levels, int *below, int *above);
 /* tile-local rows [*r0, *r1) of tile t that the plan reads (empty if r0 >= r1): what a strip
  * owner must hold / receive for that tile. */
 SR_API int sr_blend_plan_tile_rows(const sr_blend_plan *plan, int t, int *r0, int *r1);
@@ -288,6 +293,27 @@ SR_API int sr_resize_cubic_u8(sr_ctx *ctx, const uint8_t *d_src, int64_t src_str
 SR_API int sr_resize_cubic_window_u8(sr_ctx *ctx, const uint8_t *d_src, int64_t src_stride, int h,
                                      int w, int cn, int dh, int dw, int x0, int y0, int ww, int wh,
                                      uint8_t *d_dst, int64_t dst_stride);
+
+/* ---- LPIPS (quality_assessment_module.py:419-465 calculate_lpips, :197-224 _to_lpips_tensor, :135-146 model init) -------
+ * The reference delegates to the package `lpips` (requirements.txt:16): net 'alex' or 'vgg', version 0.1.  Weights are
+ * supplied by the caller (nothing is fetched): h_conv_w[i] = i-th convolution of the backbone, dense OIHW fp32,
+ * h_conv_b[i] its bias; h_lin_w[k] = the C_k weights of the k-th 1x1 `lin` layer; h_shift / h_scale = ScalingLayer
+ * constants (NULL: the package's).  AlexNet has 5 convolutions, VGG16 13.
+ * sr_lpips_u8: a, b are h x w x cn u8 images in HBM (cn 1: gray repeated, 4: alpha dropped).  The image is streamed in
+ * `tile` x `tile` input tiles (multiple of 16; <= 0: one tile) so a 200 MP image fits; tiles [tile_begin, tile_end) of the
+ * row-major tile grid are processed (tile_end < 0: all) -- ranks of a multi-GPU job take disjoint tile ranges and add the
+ * sums.  h_layer_sums[k] receives the sum of the k-th tap's lin map over those tiles; LPIPS = sum_k sums[k] / (H_k W_k)
+ * with the map sizes from sr_lpips_layer_sizes (h_hw: 5 x (H, W)). */
+enum sr_lpips_net { SR_LPIPS_ALEX = 0, SR_LPIPS_VGG = 1 };
+typedef struct sr_lpips_model sr_lpips_model;
+SR_API int sr_lpips_create(sr_ctx *ctx, int net, const float *const *h_conv_w, const float *const *h_conv_b, int n_conv,
+                           const float *const *h_lin_w, int n_lin, const float *h_shift, const float *h_scale,
+                           sr_lpips_model **out);
+SR_API int sr_lpips_destroy(sr_lpips_model *model);
+SR_API int sr_lpips_layer_sizes(int net, int h, int w, int *h_hw);
+SR_API int sr_lpips_tile_count(int h, int w, int tile, int *n_tiles);
+SR_API int sr_lpips_u8(sr_lpips_model *model, const uint8_t *d_a, int64_t stride_a, const uint8_t *d_b, int64_t stride_b,
+                       int h, int w, int cn, int tile, int tile_begin, int tile_end, double *h_layer_sums);
 
 #ifdef __cplusplus
 }

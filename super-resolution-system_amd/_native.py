@@ -63,6 +63,7 @@ _vp, _i, _i64, _sz, _dbl = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_doubl
 _pi = C.POINTER(C.c_int)
 SIGNATURES = {
     "sr_version": (_i, []),
+    "sr_source_digest": (C.c_char_p, []),
     "sr_last_error": (C.c_char_p, []),
     "sr_device_count": (_i, [_pi]),
     "sr_ctx_create": (_i, [_i, C.POINTER(_vp)]),
@@ -93,6 +94,7 @@ SIGNATURES = {
     "sr_blend_plan_create": (_i, [_vp, C.POINTER(TileRect), _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
     "sr_blend_plan_destroy": (_i, [_vp]),
     "sr_strip_tile_rows": (_i, [C.POINTER(TileRect), _i, _i, _i, _i, _i, _pi]),
+    "sr_pyramid_halo": (_i, [_i, _pi, _pi]),
     "sr_blend_plan_tile_rows": (_i, [_vp, _i, _pi, _pi]),
     "sr_blend_plan_workspace_bytes": (_i, [_vp, C.POINTER(_sz)]),
     "sr_laplacian_blend": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_i64), _vp, _i64, _vp]),
@@ -119,6 +121,11 @@ SIGNATURES = {
     "sr_rgb2gray_u8": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _i64]),
     "sr_resize_cubic_u8": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _i64, _i, _i]),
     "sr_resize_cubic_window_u8": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64]),
+    "sr_lpips_create": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), _i, C.POINTER(_vp), _i, _vp, _vp, C.POINTER(_vp)]),
+    "sr_lpips_destroy": (_i, [_vp]),
+    "sr_lpips_layer_sizes": (_i, [_i, _i, _i, _pi]),
+    "sr_lpips_tile_count": (_i, [_i, _i, _i, _pi]),
+    "sr_lpips_u8": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, C.POINTER(_dbl)]),
 }
 
 
@@ -147,25 +154,22 @@ def _preload_hip_runtime() -> None:
 
 
 def load():
-    """Load libsrhip.so (building it first if the sources are newer).  Raises SrNativeError."""
+    """Load libsrhip.so, rebuilding it first when it is missing or older than csrc/ / include/ (the .so is git-ignored
+    and travels with the tree, so an edited source must never meet yesterday's binary).  Raises SrNativeError."""
     global _lib
     with _lib_lock:
         if _lib is not None:
             return _lib
         _preload_hip_runtime()
-        if not os.path.exists(LIB_PATH):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("_sr_build", os.path.join(_HERE, "_build.py"))
+        bld = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bld)
+        if bld._stale():                 # missing, or older than a source / header: never run a stale binary silently
             try:
-                from _build import build_native  # type: ignore
-            except ImportError:
-                import importlib.util
-                spec = importlib.util.spec_from_file_location("_sr_build", os.path.join(_HERE, "_build.py"))
-                mod = importlib.util.module_from_spec(spec)
-                spec.loader.exec_module(mod)
-                build_native = mod.build_native
-            try:
-                build_native()
+                bld.build_native()
             except Exception as exc:  # noqa: BLE001
-                raise SrNativeError(f"libsrhip.so is missing and could not be built: {exc}") from exc
+                raise SrNativeError(f"libsrhip.so is missing or older than its sources and could not be rebuilt: {exc}") from exc
         try:
             lib = C.CDLL(LIB_PATH)
         except OSError as exc:
@@ -246,6 +250,13 @@ def strip_tile_rows(rects_xywh, levels: int, canvas_h: int, row_begin: int, row_
     out = (C.c_int * (2 * n))()
     check(load().sr_strip_tile_rows(rects, n, int(levels), int(canvas_h), int(row_begin), int(row_end), out))
     return [(out[2 * i], out[2 * i + 1]) for i in range(n)]
+
+
+def pyramid_halo(levels: int) -> Tuple[int, int]:
+    """Host-only: worst-case (rows below, rows above) a strip reads of a tile beyond its own rows."""
+    a, b = C.c_int(0), C.c_int(0)
+    check(load().sr_pyramid_halo(int(levels), C.byref(a), C.byref(b)))
+    return a.value, b.value
 
 
 def ssim_count(h: int, w: int, mode: str, row_begin: int = 0, row_end: Optional[int] = None) -> int:
@@ -596,6 +607,115 @@ class BlendPlan:
     def close(self):
         if getattr(self, "handle", None):
             self.ctx.lib.sr_blend_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+# ------------------------------------------------------------------------------------------
+# LPIPS (sr_lpips_*): caller-supplied weights, state-dict names of lpips.LPIPS(net) (lpips >= 0.1.4)
+# ------------------------------------------------------------------------------------------
+LPIPS_NETS = {"alex": 0, "vgg": 1}
+# convolutions of the backbones in forward order: "net.slice<S>.<index in torchvision's features>"
+LPIPS_CONV_KEYS = {
+    "alex": ["net.slice1.0", "net.slice2.3", "net.slice3.6", "net.slice4.8", "net.slice5.10"],
+    "vgg": ["net.slice1.0", "net.slice1.2", "net.slice2.5", "net.slice2.7", "net.slice3.10", "net.slice3.12",
+            "net.slice3.14", "net.slice4.17", "net.slice4.19", "net.slice4.21", "net.slice5.24", "net.slice5.26",
+            "net.slice5.28"],
+}
+LPIPS_CONV_SHAPES = {
+    "alex": [(64, 3, 11), (192, 64, 5), (384, 192, 3), (256, 384, 3), (256, 256, 3)],
+    "vgg": [(64, 3, 3), (64, 64, 3), (128, 64, 3), (128, 128, 3), (256, 128, 3), (256, 256, 3), (256, 256, 3),
+            (512, 256, 3), (512, 512, 3), (512, 512, 3), (512, 512, 3), (512, 512, 3), (512, 512, 3)],
+}
+LPIPS_TAP_CHANNELS = {"alex": (64, 192, 384, 256, 256), "vgg": (64, 128, 256, 512, 512)}
+
+
+def load_lpips_weights(path: str) -> dict:
+    """Reads a flat .npz of ``lpips.LPIPS(net).state_dict()`` arrays (numpy.load with allow_pickle=False: nothing in the
+    file is executed).  Returns {name: ndarray}."""
+    with np.load(path, allow_pickle=False) as z:
+        return {k: np.asarray(z[k]) for k in z.files}
+
+
+def lpips_pack_weights(net: str, weights: dict):
+    """Validates a state-dict of arrays against the backbone's shapes -> (conv weights, conv biases, lin weights, shift,
+    scale) as contiguous fp32 arrays in forward order.  Host only."""
+    if net not in LPIPS_NETS:
+        raise ValueError(f"LPIPS net must be 'alex' or 'vgg', got {net!r}")
+    convs_w, convs_b = [], []
+    for key, (co, ci, k) in zip(LPIPS_CONV_KEYS[net], LPIPS_CONV_SHAPES[net]):
+        if key + ".weight" not in weights or key + ".bias" not in weights:
+            raise ValueError(f"LPIPS weights for {net!r} lack {key}.weight / .bias")
+        w = np.ascontiguousarray(weights[key + ".weight"], dtype=np.float32)
+        b = np.ascontiguousarray(weights[key + ".bias"], dtype=np.float32)
+        if w.shape != (co, ci, k, k) or b.shape != (co,):
+            raise ValueError(f"LPIPS weight {key}: expected {(co, ci, k, k)} / {(co,)}, got {w.shape} / {b.shape}")
+        convs_w.append(w)
+        convs_b.append(b)
+    lins = []
+    for i, c in enumerate(LPIPS_TAP_CHANNELS[net]):
+        name = next((n for n in (f"lin{i}.model.1.weight", f"lins.{i}.model.1.weight", f"lin{i}.model.0.weight")
+                     if n in weights), None)
+        if name is None:
+            raise ValueError(f"LPIPS weights for {net!r} lack lin{i}.model.1.weight")
+        lw = np.ascontiguousarray(np.asarray(weights[name], dtype=np.float32).reshape(-1))
+        if lw.shape != (c,):
+            raise ValueError(f"LPIPS weight {name}: expected {c} values, got {lw.shape}")
+        lins.append(lw)
+    shift = np.ascontiguousarray(weights.get("scaling_layer.shift", np.array([-.030, -.088, -.188])), dtype=np.float32).reshape(-1)
+    scale = np.ascontiguousarray(weights.get("scaling_layer.scale", np.array([.458, .448, .450])), dtype=np.float32).reshape(-1)
+    if shift.shape != (3,) or scale.shape != (3,):
+        raise ValueError("LPIPS scaling_layer.shift / .scale must hold 3 values")
+    return convs_w, convs_b, lins, shift, scale
+
+
+class LpipsModel:
+    """sr_lpips_model: one backbone + lin layers resident on the GPU."""
+
+    def __init__(self, ctx: Context, net: str, weights: dict):
+        convs_w, convs_b, lins, shift, scale = lpips_pack_weights(net, weights)
+        self.ctx, self.net = ctx, net
+        n = len(convs_w)
+        pw = (C.c_void_p * n)(*[a.ctypes.data for a in convs_w])
+        pb = (C.c_void_p * n)(*[a.ctypes.data for a in convs_b])
+        pl = (C.c_void_p * 5)(*[a.ctypes.data for a in lins])
+        h = C.c_void_p()
+        check(ctx.lib.sr_lpips_create(ctx.handle, LPIPS_NETS[net], pw, pb, n, pl, 5, shift.ctypes.data_as(C.c_void_p),
+                                      scale.ctypes.data_as(C.c_void_p), C.byref(h)))
+        self.handle = h
+
+    def layer_sizes(self, h: int, w: int):
+        out = (C.c_int * 10)()
+        check(self.ctx.lib.sr_lpips_layer_sizes(LPIPS_NETS[self.net], int(h), int(w), out))
+        return [(out[2 * i], out[2 * i + 1]) for i in range(5)]
+
+    def tile_count(self, h: int, w: int, tile: int) -> int:
+        n = C.c_int(0)
+        check(self.ctx.lib.sr_lpips_tile_count(int(h), int(w), int(tile), C.byref(n)))
+        return n.value
+
+    def layer_sums(self, d_a: int, stride_a: int, d_b: int, stride_b: int, h: int, w: int, cn: int, tile: int = 2048,
+                   tile_begin: int = 0, tile_end: int = -1):
+        """Per-tap sums of the lin maps over tiles [tile_begin, tile_end) (additive across disjoint tile ranges)."""
+        out = (C.c_double * 5)()
+        check(self.ctx.lib.sr_lpips_u8(self.handle, C.c_void_p(d_a), int(stride_a), C.c_void_p(d_b), int(stride_b), int(h),
+                                       int(w), int(cn), int(tile), int(tile_begin), int(tile_end), out))
+        return [out[i] for i in range(5)]
+
+    def value(self, d_a: int, stride_a: int, d_b: int, stride_b: int, h: int, w: int, cn: int, tile: int = 2048,
+              per_layer: bool = False):
+        sums = self.layer_sums(d_a, stride_a, d_b, stride_b, h, w, cn, tile)
+        vals = [s / (lh * lw) for s, (lh, lw) in zip(sums, self.layer_sizes(h, w))]
+        return (float(sum(vals)), vals) if per_layer else float(sum(vals))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.ctx.lib.sr_lpips_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

@@ -24,57 +24,12 @@
 #include <string>
 #include <vector>
 
-#include "sr_internal.h"
-
-#define HIPCHK(expr)                                                                               \
-    do {                                                                                           \
-        hipError_t e_ = (expr);                                                                    \
-        if (e_ != hipSuccess)                                                                      \
-            return sr_set_error(SR_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
-                                __LINE__);                                                         \
-    } while (0)
+#include "sr_ctx.h"
 
 // ---------------------------------------------------------------------------------------------
-// context
+// context (struct, Guard, ProfScope: sr_ctx.h)
 // ---------------------------------------------------------------------------------------------
-struct ProfPair {
-    int name_id;
-    hipEvent_t a, b;
-};
-
-// A small device table with a host shadow of what was last uploaded into it: per-step descriptor tables (tile
-// pointers, strides, rectangles) rarely change between calls, and a host->device copy between two kernels costs a
-// stream bubble of several microseconds -- identical content is not uploaded again.
-struct CachedTable {
-    void *d = nullptr;
-    size_t cap = 0;
-    std::vector<char> shadow;
-};
-
-struct sr_ctx {
-    int device = 0;
-    int num_cu = 256;               // compute units of the device (launch-shape heuristics)
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    std::recursive_mutex mu;
-    bool prof = false;
-    std::string prof_only;          // when not empty: the one kernel family that is timed
-    std::vector<std::string> prof_names;
-    std::vector<ProfPair> prof_pairs;
-    std::vector<hipEvent_t> ev_pool;
-    // small reusable device scratch (resize tables, reduction partials, result words)
-    void *scratch = nullptr;
-    size_t scratch_bytes = 0;
-    // host copies of small tables handed to hipMemcpyAsync; released at the next stream sync
-    std::vector<std::vector<char>> pending_host;
-    size_t pending_bytes = 0;
-    CachedTable extract_tab;                            // tile-extract descriptors
-    CachedTable resize_tab;                             // cubic tables of the resized assessment
-    CachedTable cubic_tab;                              // cubic tables of sr_resize_cubic_u8
-};
-
-// Enqueue a small host->device table upload whose source stays alive until the next sync.
-static hipError_t upload_small(sr_ctx *c, void *d_dst, const void *h_src, size_t bytes)
+hipError_t upload_small(sr_ctx *c, void *d_dst, const void *h_src, size_t bytes)
 {
     // bound what a caller that never synchronises can pile up: drain the stream once 32 MB of table copies are parked
     c->pending_bytes += bytes;
@@ -88,18 +43,14 @@ static hipError_t upload_small(sr_ctx *c, void *d_dst, const void *h_src, size_t
     return hipMemcpyAsync(d_dst, c->pending_host.back().data(), bytes, hipMemcpyHostToDevice, c->stream);
 }
 
-static hipError_t stream_sync(sr_ctx *c);
-
-// Upload into a fixed destination unless `shadow` shows the same bytes are already there.
-static hipError_t upload_if_changed(sr_ctx *c, void *d_dst, const void *h_src, size_t bytes, std::vector<char> &shadow)
+hipError_t upload_if_changed(sr_ctx *c, void *d_dst, const void *h_src, size_t bytes, std::vector<char> &shadow)
 {
     if (shadow.size() == bytes && bytes > 0 && memcmp(shadow.data(), h_src, bytes) == 0) return hipSuccess;
     shadow.assign((const char *)h_src, (const char *)h_src + bytes);
     return upload_small(c, d_dst, h_src, bytes);
 }
 
-// Same with a table that owns (and grows) its device buffer.
-static hipError_t upload_cached(sr_ctx *c, CachedTable &t, const void *h_src, size_t bytes)
+hipError_t upload_cached(sr_ctx *c, CachedTable &t, const void *h_src, size_t bytes)
 {
     if (bytes > t.cap) {
         if (t.d) {
@@ -117,7 +68,7 @@ static hipError_t upload_cached(sr_ctx *c, CachedTable &t, const void *h_src, si
     return upload_if_changed(c, t.d, h_src, bytes, t.shadow);
 }
 
-static hipError_t stream_sync(sr_ctx *c)
+hipError_t stream_sync(sr_ctx *c)
 {
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) {
@@ -133,7 +84,7 @@ static hipError_t stream_sync(sr_ctx *c)
 struct sr_blend_plan;
 static std::mutex g_reg_mu;
 static std::set<const void *> g_live_ctx, g_live_plan;
-static bool ctx_is_live(const sr_ctx *c)
+bool ctx_is_live(const sr_ctx *c)
 {
     std::lock_guard<std::mutex> lk(g_reg_mu);
     return c && g_live_ctx.count(c) != 0;
@@ -144,7 +95,7 @@ static bool plan_is_live(const sr_blend_plan *p)
     return p && g_live_plan.count(p) != 0;
 }
 
-static int ctx_scratch(sr_ctx *c, size_t bytes, void **out)
+int ctx_scratch(sr_ctx *c, size_t bytes, void **out)
 {
     if (bytes > c->scratch_bytes) {
         if (c->scratch) {
@@ -161,29 +112,7 @@ static int ctx_scratch(sr_ctx *c, size_t bytes, void **out)
     return SR_OK;
 }
 
-struct Guard {
-    sr_ctx *c;
-    int prev = -1;
-    bool ok = true;
-    explicit Guard(sr_ctx *ctx) : c(ctx)
-    {
-        c->mu.lock();
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        if (prev != c->device && hipSetDevice(c->device) != hipSuccess) ok = false;
-    }
-    ~Guard()
-    {
-        if (prev >= 0 && prev != c->device) (void)hipSetDevice(prev);
-        c->mu.unlock();
-    }
-};
-
-#define CTX_ENTER(ctx)                                                               \
-    if (!ctx_is_live(ctx)) return sr_set_error(SR_ERR_INVALID_ARG, "%s: null or destroyed context", __func__); \
-    Guard guard_(ctx);                                                               \
-    if (!guard_.ok) return sr_set_error(SR_ERR_HIP, "%s: hipSetDevice(%d) failed", __func__, (ctx)->device)
-
-static hipEvent_t prof_event(sr_ctx *c)
+hipEvent_t prof_event(sr_ctx *c)
 {
     if (!c->ev_pool.empty()) {
         hipEvent_t e = c->ev_pool.back();
@@ -195,37 +124,7 @@ static hipEvent_t prof_event(sr_ctx *c)
     return e;
 }
 
-struct ProfScope {
-    sr_ctx *c;
-    ProfPair p{};
-    bool on;
-    ProfScope(sr_ctx *ctx, const char *name) : c(ctx), on(ctx->prof)
-    {
-        if (on && !c->prof_only.empty() && c->prof_only != name) on = false;
-        if (!on) return;
-        int id = -1;
-        for (size_t i = 0; i < c->prof_names.size(); ++i)
-            if (c->prof_names[i] == name) id = (int)i;
-        if (id < 0) {
-            c->prof_names.push_back(name);
-            id = (int)c->prof_names.size() - 1;
-        }
-        p.name_id = id;
-        p.a = prof_event(c);
-        p.b = prof_event(c);
-        (void)hipEventRecord(p.a, c->stream);
-    }
-    ~ProfScope()
-    {
-        if (!on) return;
-        (void)hipEventRecord(p.b, c->stream);
-        c->prof_pairs.push_back(p);
-    }
-};
-
-static const double *reduce_partials(sr_ctx *ctx, const double *part, long long n, int ncomp, double *buf0, double *buf1);
-
-static int check_launch(const char *what)
+int check_launch(const char *what)
 {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return sr_set_error(SR_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
@@ -3528,7 +3427,7 @@ __global__ void k_assess_store(const double *__restrict__ g, const double *__res
 }
 
 // reduce part[n][ncomp] -> returns pointer (inside the two ping-pong buffers) holding ncomp results
-static const double *reduce_partials(sr_ctx *ctx, const double *part, long long n, int ncomp, double *buf0, double *buf1)
+const double *reduce_partials(sr_ctx *ctx, const double *part, long long n, int ncomp, double *buf0, double *buf1)
 {
     const double *src = part;
     double *dst = buf0;

@@ -21,7 +21,12 @@ int sr_set_error(int code, const char *fmt, ...)
 
 extern "C" {
 
-int sr_version(void) { return 100; }
+int sr_version(void) { return 200; }
+
+#ifndef SR_SOURCE_DIGEST
+#define SR_SOURCE_DIGEST "unknown"
+#endif
+const char *sr_source_digest(void) { return SR_SOURCE_DIGEST; }
 
 const char *sr_last_error(void) { return g_err; }
 
@@ -145,6 +150,23 @@ int sr_strip_tile_rows(const sr_tile_rect *h_tiles, int n, int levels, int canva
         h_rows[2 * t] = lv.gw[0].a;
         h_rows[2 * t + 1] = lv.gw[0].b;
     }
+    return SR_OK;
+}
+
+// Worst-case halo of sr_plan_windows, derived from its two recurrences (levels whose height is >= 8; smaller levels
+// are taken whole).  Up chain, level i-1 -> i: rows [a, b] of R_{i-1} read rows floor(a/2) - 1 .. floor(b/2) + 1 of R_i;
+// in level-0 units that is at most 1.5 * 2^i rows further below and 2^i further above.  Down chain, level i+1 -> i:
+// rows [a, b] of G_{i+1} read rows 2a - 2 .. 2b + 2 of G_i: 2 * 2^i further on both sides.  Summed over a pyramid of
+// L levels: below = 1.5 (2^L - 2) + 2 (2^(L-1) - 1) = 2.5 * 2^L - 5, above = (2^L - 2) + (2^L - 2) + 1 (half-open end).
+// L = 6: 155 rows below, 125 above (the survey's "~128" counted the down chain only).
+int sr_pyramid_halo(int levels, int *below, int *above)
+{
+    if (levels < 1 || levels > SR_MAX_LEVELS || !below || !above)
+        return sr_set_error(SR_ERR_INVALID_ARG, "sr_pyramid_halo: bad arguments");
+    const long long p = 1LL << levels;
+    *below = (int)((5 * p) / 2 - 5);
+    *above = (int)(2 * p - 3);
+    if (levels == 1) *below = *above = 0;
     return SR_OK;
 }
 

@@ -108,7 +108,12 @@ def workload_geometry(name: str) -> Geometry:
 COST_ASSESS = 10.5     # per canvas pixel (fused PSNR + 3 x SSIM; includes its tail effect on strips)
 COST_GATHER = 4.0      # per tile pixel visited by the canvas gather
 COST_PYRAMID = 6.6     # per tile pixel of the pyramid chains (extract, down, up) -- also paid for the halo rows
-PYRAMID_HALO = 150     # rows of level 0 a strip recomputes beyond each of its borders (6 levels)
+
+
+def pyramid_halo(levels: int = 6) -> int:
+    """Rows of level 0 a strip recomputes beyond each of its borders: the analytic worst case of the window planner
+    (sr_pyramid_halo; 155 below / 125 above at 6 levels) -- the cost model charges the larger side."""
+    return max(_native.pyramid_halo(levels))
 
 
 def strip_bounds(canvas_h: int, world: int, geo: Optional["Geometry"] = None) -> List[int]:
@@ -125,8 +130,10 @@ def strip_bounds(canvas_h: int, world: int, geo: Optional["Geometry"] = None) ->
     cum_can = np.concatenate([[0.0], np.cumsum(COST_ASSESS * geo.canvas_w + COST_GATHER * cover)])
     cum_pyr = np.concatenate([[0.0], np.cumsum(COST_PYRAMID * cover)])
 
+    halo = pyramid_halo(geo.levels)
+
     def cost(a: int, b: int) -> float:
-        lo, hi = max(a - PYRAMID_HALO, 0), min(b + PYRAMID_HALO, canvas_h)
+        lo, hi = max(a - halo, 0), min(b + halo, canvas_h)
         return float(cum_can[b] - cum_can[a] + cum_pyr[hi] - cum_pyr[lo])
 
     def place(target: float) -> List[int]:
@@ -280,14 +287,11 @@ def exchange_tile_rows(plan: ExchangePlan, rank: int, local_tiles: Dict[int, "ob
         ops.append(dist.P2POp(dist.isend, local_tiles[t][a:b], peer, group))
     for (peer, t, a, b) in recvs:
         ops.append(dist.P2POp(dist.irecv, recv_bufs[t], peer, group))
-    try:
-        return dist.batch_isend_irecv(ops)
-    except (RuntimeError, ValueError) as exc:          # a backend without grouped point-to-point: same transfers one by one
-        import sys
-        print(f"[device_pipeline] batch_isend_irecv unavailable ({exc}); posting the transfers individually", file=sys.stderr)
-        works = [dist.isend(local_tiles[t][a:b], peer, group=group, tag=t) for (peer, t, a, b) in sends]
-        works += [dist.irecv(recv_bufs[t], peer, group=group, tag=t) for (peer, t, a, b) in recvs]
-        return works
+    # One grouped batch (ncclGroupStart / End around every ncclSend / ncclRecv): inside a group NCCL matches the
+    # transfers of a pair whatever their posting order, so two strips that send to each other cannot deadlock.  There is
+    # deliberately no ungrouped fallback: posted one by one, each rank would queue its sends ahead of its receives on the
+    # pair's communicator stream and multi-MB transfers would wait on each other forever -- a failure here must surface.
+    return dist.batch_isend_irecv(ops)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -11,14 +11,19 @@ for ``multiscale=True``, cropped mean); one that rejects it gives branch B (``_c
 for both).  ``ssim_branch`` selects it ('A' default).  ``gray_shift`` selects OpenCV's 15-bit (>= 4.x,
 default) or 14-bit RGB2GRAY constants.
 
-Not available offline: LPIPS (``lpips`` package + torchvision weights) -- ``lpips_model_vgg`` stays
-None exactly like the reference when the import fails, so ``evaluate_full_reference`` omits the LPIPS
-keys and ``calculate_lpips`` raises RuntimeError.  NIQE / BRISQUE / commercial heuristics are outside
+LPIPS (quality_assessment_module.py:135-146,197-224,419-465): the AlexNet / VGG16 forward of the ``lpips`` package
+runs as hand-written fp32 MFMA convolutions (csrc/sr_lpips.hip), streamed in tiles so a 200 MP pair fits.  The
+reference's constructor downloads pretrained weights by model name; this one never fetches anything: weights come
+from ``lpips_weights={'vgg': <.npz path or dict>, 'alex': ...}`` (or SR_LPIPS_WEIGHTS_VGG / SR_LPIPS_WEIGHTS_ALEX),
+a flat .npz of ``lpips.LPIPS(net).state_dict()`` arrays read with allow_pickle=False.  Without weights
+``lpips_model_vgg`` stays None exactly like the reference when its import fails: ``evaluate_full_reference`` omits
+the LPIPS keys and ``calculate_lpips`` raises RuntimeError.  NIQE / BRISQUE / commercial heuristics are outside
 the tile -> blend -> assess path; ``evaluate_commercial`` returns an empty, labelled result so
 main.process keeps its report structure.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from enum import Enum
 from typing import Any, Dict, List, Optional, Tuple, Union
@@ -102,7 +107,7 @@ class _DevImage:
 class QualityAssessmentModule:
     def __init__(self, device: str = 'cpu', thresholds: Optional[QualityThresholds] = None,
                  scale_config: Optional[ScaleConfig] = None, gpu_index: int = 0, ssim_branch: str = 'A',
-                 gray_shift: int = 15):
+                 gray_shift: int = 15, lpips_weights: Optional[Dict[str, Any]] = None, lpips_tile: int = 2048):
         # the reference's `device` only places the LPIPS networks; the metrics here always run on the GPU
         self.device = device
         self.thresholds = thresholds or QualityThresholds()
@@ -112,13 +117,29 @@ class QualityAssessmentModule:
             raise ValueError("ssim_branch must be 'A' or 'B'")
         self.ssim_branch = ssim_branch
         self.gray_shift = gray_shift
-        self.lpips_model_vgg = None      # weights are not available offline
+        self.lpips_tile = int(lpips_tile)
+        self.lpips_model_vgg = None      # stay None without caller-supplied weights (nothing is fetched)
         self.lpips_model_alex = None
+        self._init_lpips_models(lpips_weights)
         self._niqe_available = False
         self._brisque_available = False
 
     def _ctx(self) -> "_native.Context":
         return _native.default_context(self.gpu_index)
+
+    def _init_lpips_models(self, lpips_weights: Optional[Dict[str, Any]] = None) -> None:
+        """quality_assessment_module.py:135-146 without the download: build the GPU models from caller-supplied
+        state-dict arrays ({'vgg': path | dict, 'alex': path | dict}; env SR_LPIPS_WEIGHTS_<NET> as a default)."""
+        src = dict(lpips_weights or {})
+        for net in ("vgg", "alex"):
+            if net not in src and os.environ.get(f"SR_LPIPS_WEIGHTS_{net.upper()}"):
+                src[net] = os.environ[f"SR_LPIPS_WEIGHTS_{net.upper()}"]
+        for net, w in src.items():
+            if net not in ("vgg", "alex"):
+                raise ValueError(f"lpips_weights: unknown net {net!r}")
+            if isinstance(w, (str, os.PathLike)):
+                w = _native.load_lpips_weights(os.fspath(w))
+            setattr(self, f"lpips_model_{net}", _native.LpipsModel(self._ctx(), net, w))
 
     # -- preprocessing (quality_assessment_module.py:169-195, 304-308) --------------------------------
     def _preprocess_image(self, image: Any, to_tensor: bool = False) -> np.ndarray:
@@ -240,8 +261,40 @@ class QualityAssessmentModule:
         finally:
             da.free(); db.free()
 
+    def _to_lpips_tensor(self, image: np.ndarray) -> np.ndarray:
+        """quality_assessment_module.py:197-224 as an ndarray (1, 3, H, W) in [-1, 1]; for inspection -- the GPU path
+        applies the same arithmetic inside the stem convolution and never materialises this tensor."""
+        img = np.asarray(image).astype(np.float32) / 255.0
+        if img.ndim == 2:
+            img = np.stack([img, img, img], axis=-1)
+        elif img.shape[2] == 1:
+            img = np.repeat(img, 3, axis=-1)
+        elif img.shape[2] == 4:
+            img = img[:, :, :3]
+        return np.ascontiguousarray(img.transpose(2, 0, 1))[None] * np.float32(2.0) - np.float32(1.0)
+
+    def _lpips_dev(self, a: _DevImage, b: _DevImage, net: str) -> float:
+        model = self.lpips_model_vgg if net == 'vgg' else self.lpips_model_alex
+        if model is None:
+            raise RuntimeError("LPIPS模型未成功加载")
+        h, w = min(a.h, b.h), min(a.w, b.w)                    # common top-left rectangle (:449-453)
+        return model.value(a.ptr, a.stride, b.ptr, b.stride, h, w, a.cn, tile=self.lpips_tile)
+
     def calculate_lpips(self, img1: np.ndarray, img2: np.ndarray, net: str = 'vgg') -> float:
-        raise RuntimeError("LPIPS模型未成功加载")   # same error the reference raises without its models
+        if self.lpips_model_vgg is None:
+            raise RuntimeError("LPIPS模型未成功加载")   # same error the reference raises without its models
+        a = self._require_u8(self._preprocess_image(img1), "calculate_lpips")
+        b = self._require_u8(self._preprocess_image(img2), "calculate_lpips")
+        cn_a = a.shape[2] if a.ndim == 3 else 1
+        cn_b = b.shape[2] if b.ndim == 3 else 1
+        if cn_a != cn_b or cn_a not in (1, 3, 4):
+            raise ValueError(f"calculate_lpips: channel layouts {a.shape} vs {b.shape}")
+        ctx = self._ctx()
+        da, db = _DevImage(ctx, a), _DevImage(ctx, b)
+        try:
+            return float(self._lpips_dev(da, db, net))
+        finally:
+            da.free(); db.free()
 
     # -- full-reference evaluation (quality_assessment_module.py:467-609) ------------------------------------
     def evaluate_full_reference(self, original: np.ndarray, upscaled: np.ndarray, scale_factor: int = 4) -> Dict[str, float]:
@@ -269,6 +322,11 @@ class QualityAssessmentModule:
                 metrics['ms_ssim'] = float(self._ssim_dev(d_o, d_u, True, 255.0))
             metrics['psnr_level'] = self._assess_psnr(metrics['psnr'])
             metrics['ssim_level'] = self._assess_ssim(metrics['ms_ssim'])
+            if self.lpips_model_vgg is not None:               # only when weights were given (:508-511)
+                metrics['lpips_vgg'] = float(self._lpips_dev(d_o, d_u, 'vgg'))
+                if self.lpips_model_alex is not None:
+                    metrics['lpips_alex'] = float(self._lpips_dev(d_o, d_u, 'alex'))
+                metrics['lpips_level'] = self._assess_lpips(metrics['lpips_vgg'])
             metrics['overall_score'] = self._calculate_overall_score(metrics)
             return metrics
         finally:

@@ -64,7 +64,21 @@ def test_invalid_arguments_map_to_value_error():
 def test_strip_windows_host():
     rows = _native.strip_tile_rows([(0, 0, 2000, 3000)], 6, 3000, 1400, 1600)
     (a, b), = rows
-    assert 1400 - 160 <= a <= 1400 and 1600 <= b <= 1600 + 160
+    below, above = _native.pyramid_halo(6)
+    assert (below, above) == (155, 125)                 # 2.5 * 2^L - 5 and 2 * 2^L - 3, derived in sr_pyramid_halo
+    assert 1400 - below <= a <= 1400 and 1600 <= b <= 1600 + above
+    # the bound is tight below and never exceeded: random strips of random tiles
+    rnd = np.random.default_rng(5)
+    worst = [0, 0]
+    for _ in range(3000):
+        h, w, y0 = int(rnd.integers(600, 5000)), int(rnd.integers(300, 3000)), int(rnd.integers(0, 3000))
+        ch = y0 + h + int(rnd.integers(0, 400))
+        s0 = int(rnd.integers(0, ch - 1)); s1 = int(rnd.integers(s0 + 1, ch + 1))
+        (r0, r1), = _native.strip_tile_rows([(0, y0, w, h)], 6, ch, s0, s1)
+        lo, hi = max(s0 - y0, 0), min(s1 - y0, h)
+        if lo < hi:
+            worst = [max(worst[0], lo - r0), max(worst[1], r1 - hi)]
+    assert worst[0] <= below and worst[1] <= above and worst[0] >= below - 8
     assert _native.strip_tile_rows([(0, 0, 100, 100), (0, 500, 100, 100)], 6, 600, 0, 100)[1] == (0, 0)
     full = _native.strip_tile_rows([(0, 0, 640, 480)], 6, 480, 0, 480)
     assert full == [(0, 480)]

@@ -1,0 +1,133 @@
+"""GPU parity for LPIPS: the fp32-MFMA AlexNet / VGG16 forward of csrc/sr_lpips.hip vs the torch-CPU
+restatement of the published lpips 0.1.4 forward (oracle/lpips_oracle.py) on the same seeded SYNTHETIC weights.
+
+PARITY UNPINNED: the reference delegates to the `lpips` package; neither it nor its pretrained weights exist offline
+and the reference holds no LPIPS fixture.  What is checked: same value as the restatement (1e-4 relative, the
+north-star bar for float scores; fp32 convolutions with a different summation order), tiled == untiled, gray / RGBA
+inputs, additivity over tile ranges, and the QualityAssessmentModule surface (keys only with weights)."""
+import numpy as np
+import pytest
+
+from oracle import lpips_oracle as lo
+
+pytestmark = pytest.mark.gpu
+REL = 1e-4
+
+
+def _pair(rng, h, w, cn=3, sigma=9.0):
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = (128 + 64 * np.sin(xx / 37.0) + 48 * np.cos(yy / 23.0))
+    shape = (h, w) if cn == 0 else (h, w, cn)
+    base = base if cn == 0 else base[..., None]
+    a = np.clip(base + rng.integers(-20, 21, shape), 0, 255).astype(np.uint8)
+    b = np.clip(a.astype(np.float32) + rng.normal(0, sigma, shape), 0, 255).astype(np.uint8)
+    return a, b
+
+
+@pytest.fixture(scope="module")
+def models(ctx):
+    import _native
+    out = {}
+    for net in ("alex", "vgg"):
+        w = lo.synthetic_weights(net)
+        out[net] = (_native.LpipsModel(ctx, net, w), w)
+    yield out
+    for m, _ in out.values():
+        m.close()
+
+
+def _gpu(ctx, model, a, b, tile=0, per_layer=True):
+    cn = a.shape[2] if a.ndim == 3 else 1
+    da, db = ctx.upload(a), ctx.upload(b)
+    try:
+        return model.value(da.ptr, a.shape[1] * cn, db.ptr, b.shape[1] * cn, a.shape[0], a.shape[1], cn, tile=tile,
+                           per_layer=per_layer)
+    finally:
+        da.free(); db.free()
+
+
+@pytest.mark.parametrize("net,shape", [("alex", (1000, 1024)), ("alex", (257, 193)), ("vgg", (600, 800)), ("vgg", (131, 77))])
+def test_lpips_matches_oracle(ctx, rng, models, net, shape):
+    model, w = models[net]
+    a, b = _pair(rng, *shape)
+    got, got_layers = _gpu(ctx, model, a, b)
+    want, want_layers = lo.lpips(a, b, net, w, per_layer=True)
+    assert model.layer_sizes(*shape) == lo.layer_sizes(net, *shape)
+    assert want > 1e-3                                   # a meaningful distance, not a sum of zeros
+    for g, x in zip(got_layers, want_layers):
+        assert abs(g - x) <= REL * abs(x), (net, got_layers, want_layers)
+    assert abs(got - want) <= REL * abs(want)
+
+
+@pytest.mark.parametrize("net", ["alex", "vgg"])
+def test_lpips_tiled_equals_untiled(ctx, rng, models, net):
+    """Tile streaming recomputes the receptive-field halo and pads with zeros only at the true image border, so the
+    features are the untiled forward's; only the order of the fp64 spatial sums differs."""
+    model, _ = models[net]
+    a, b = _pair(rng, 300, 420)
+    whole, wl = _gpu(ctx, model, a, b, tile=0)
+    for tile in (64, 128, 304):
+        got, gl = _gpu(ctx, model, a, b, tile=tile)
+        for g, x in zip(gl, wl):
+            assert abs(g - x) <= 1e-9 * abs(x), (tile, gl, wl)
+    # additive over disjoint tile ranges (what the ranks of a multi-GPU job add up)
+    n = model.tile_count(300, 420, 128)
+    assert n == 3 * 4
+    da, db = ctx.upload(a), ctx.upload(b)
+    try:
+        parts = [model.layer_sums(da.ptr, 420 * 3, db.ptr, 420 * 3, 300, 420, 3, 128, lo_, hi_) for lo_, hi_ in ((0, 5), (5, 7), (7, n))]
+        full = model.layer_sums(da.ptr, 420 * 3, db.ptr, 420 * 3, 300, 420, 3, 128)
+    finally:
+        da.free(); db.free()
+    for k in range(5):
+        assert abs(sum(p[k] for p in parts) - full[k]) <= 1e-12 * abs(full[k])
+
+
+@pytest.mark.parametrize("net", ["alex", "vgg"])
+def test_lpips_gray_and_alpha(ctx, rng, models, net):
+    """_to_lpips_tensor: gray is repeated to three channels, the alpha channel is dropped (:213-218)."""
+    model, w = models[net]
+    a, b = _pair(rng, 96, 160, cn=0)
+    got = _gpu(ctx, model, a, b, per_layer=False)
+    want = lo.lpips(a, b, net, w)
+    assert abs(got - want) <= REL * abs(want)
+    a4, b4 = _pair(rng, 96, 160, cn=4)
+    got = _gpu(ctx, model, a4, b4, per_layer=False)
+    want = lo.lpips(a4, b4, net, w)
+    assert abs(got - want) <= REL * abs(want)
+    assert _gpu(ctx, model, a4, a4, per_layer=False) == 0.0
+
+
+def test_lpips_too_small_raises(ctx, models):
+    import _native
+    a = np.zeros((12, 40, 3), np.uint8)
+    with pytest.raises(_native.SrShapeError):
+        _gpu(ctx, models["vgg"][0], a, a)
+    with pytest.raises(_native.SrShapeError):
+        _gpu(ctx, models["alex"][0], np.zeros((30, 64, 3), np.uint8), np.zeros((30, 64, 3), np.uint8))
+
+
+def test_quality_module_lpips_surface(rng, tmp_path):
+    """calculate_lpips / evaluate_full_reference (quality_assessment_module.py:419-465, 508-511, 590-609): LPIPS keys
+    appear only when weights were given; the overall score then averages three terms; weights load from a flat .npz."""
+    from quality_assessment_module import QualityAssessmentModule
+    a, b = _pair(rng, 200, 240)
+    plain = QualityAssessmentModule()
+    with pytest.raises(RuntimeError):
+        plain.calculate_lpips(a, b)
+    base = plain.evaluate_full_reference(a, b)
+    assert not any(k.startswith("lpips") for k in base)
+    wv, wa = lo.synthetic_weights("vgg"), lo.synthetic_weights("alex")
+    path = tmp_path / "vgg.npz"
+    np.savez(path, **wv)
+    qam = QualityAssessmentModule(lpips_weights={"vgg": str(path), "alex": wa}, lpips_tile=128)
+    v = qam.calculate_lpips(a, b, net="vgg")
+    assert abs(v - lo.lpips(a, b, "vgg", wv)) <= REL * v
+    al = qam.calculate_lpips(a, b[:190, :230], net="alex")           # cropped to the common rectangle
+    assert abs(al - lo.lpips(a, b[:190, :230], "alex", wa)) <= REL * al
+    full = qam.evaluate_full_reference(a, b)
+    assert abs(full["lpips_vgg"] - v) <= 1e-12 and "lpips_alex" in full and full["lpips_level"] in ("excellent", "good", "fair", "poor")
+    want = np.mean([min(100, max(0, full["psnr"])), full["ms_ssim"] * 100, max(0, (1 - full["lpips_vgg"]) * 100)])
+    assert abs(full["overall_score"] - want) < 1e-9
+    for k in ("psnr", "ssim", "ms_ssim"):
+        assert full[k] == base[k]
