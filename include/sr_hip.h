@@ -47,7 +47,10 @@ enum sr_status {
 /* tiling_module.PaddingMode (tiling_module.py:40-45) */
 enum sr_pad_mode { SR_PAD_MIRROR = 0, SR_PAD_REPLICATE = 1, SR_PAD_REFLECT = 2, SR_PAD_CONSTANT = 3 };
 /* blending_module.WeightType (blending_module.py:52-56) */
-enum sr_weight_type { SR_W_LINEAR = 0, SR_W_COSINE = 1, SR_W_SIGMOID = 2 };
+enum sr_weight_type { SR_W_LINEAR = 0, SR_W_COSINE = 1, SR_W_SIGMOID = 2,
+                      /* every weight 1: what BlendingModule.feather_blend's distance-transform weights evaluate to
+                       * (blending_module.py:1313-1337: cv2.distanceTransform of an all-ones mask; see sr_weighted_blend) */
+                      SR_W_ONES = 3 };
 /* calculate_ssim branches (quality_assessment_module.py:365-417) */
 enum sr_ssim_mode { SR_SSIM_UNIFORM7 = 0, SR_SSIM_GAUSS11 = 1, SR_SSIM_SIMPLE = 2 };
 enum sr_dtype { SR_U8 = 0, SR_F32 = 1 };
@@ -115,6 +118,11 @@ SR_API int sr_weight_lut(int fw, int weight_type, float *h_lut);
 SR_API int sr_tile_extract_pad(sr_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, int cn,
                                int64_t img_stride, const int *h_xywh, int n, int block_size,
                                int pad_mode, uint8_t *d_tiles);
+/* TilingModule.split_image's complexity_score = np.std(cv2.cvtColor(tile, COLOR_BGR2GRAY)) (tiling_module.py:746-749) for
+ * n RGB u8 tiles of h x w that live in HBM, tile i at d_tiles + i * tile_bytes: h_sums[2 i], h_sums[2 i + 1] receive the exact
+ * sums of gray and gray^2 (swap_rb != 0: the reference's BGR constants on RGB data).  No pixel leaves the GPU. */
+SR_API int sr_gray_moments_u8(sr_ctx *ctx, const uint8_t *d_tiles, int n, int64_t tile_bytes, int64_t stride, int h, int w,
+                              int gray_shift, int swap_rb, uint64_t *h_sums);
 /* Plain overlap-tile extract (no padding): tile i = img[y:y+h, x:x+w] into d_tiles[i] with row
  * stride tile_strides[i]; used by the benchmark's output-space tile stage. */
 SR_API int sr_tile_extract(sr_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, int cn,
@@ -293,6 +301,19 @@ SR_API int sr_resize_cubic_u8(sr_ctx *ctx, const uint8_t *d_src, int64_t src_str
 SR_API int sr_resize_cubic_window_u8(sr_ctx *ctx, const uint8_t *d_src, int64_t src_stride, int h,
                                      int w, int cn, int dh, int dw, int x0, int y0, int ww, int wh,
                                      uint8_t *d_dst, int64_t dst_stride);
+
+/* ---- BlendingModule.color_correction (blending_module.py:969-1146) ---------------------------------
+ * sr_histogram_u8: per-channel 256-bin histogram (np.histogram(ch, 256, [0, 256]) of u8 data), h_hist = cn x 256 counts.
+ * The matching itself is 256-entry bookkeeping on the host (CDFs in float64, argmin; or the mean / std affine map of
+ * _mean_std_matching) and arrives here as a per-channel table h_glut[c][v] = corrected float value of source value v.
+ * sr_color_correct_u8: out = astype(u8)(clip(corrected, 0, 255)) with corrected = h_glut[c][img]; with local_filter != 0
+ * corrected goes through _simple_guided_filter(guide = corrected, src = img, radius, eps) first (:1110-1146: five
+ * cv2.blur((radius, radius)) box means -- anchor radius / 2, REFLECT_101 -- and fp32 element-wise algebra; the
+ * cv2.ximgproc.guidedFilter branch of :1098-1105 is not built).  radius 1..16. */
+SR_API int sr_histogram_u8(sr_ctx *ctx, const uint8_t *d_img, int64_t stride, int h, int w, int cn, uint64_t *h_hist);
+SR_API int sr_color_correct_u8(sr_ctx *ctx, const uint8_t *d_img, int64_t stride, int h, int w, int cn,
+                               const float *h_glut, int local_filter, int radius, float eps, uint8_t *d_out,
+                               int64_t out_stride);
 
 /* ---- LPIPS (quality_assessment_module.py:419-465 calculate_lpips, :197-224 _to_lpips_tensor, :135-146 model init) -------
  * The reference delegates to the package `lpips` (requirements.txt:16): net 'alex' or 'vgg', version 0.1.  Weights are

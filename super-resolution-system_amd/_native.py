@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libsrhip.so")
 SR_OK = 0
 SR_ERR_INVALID_ARG, SR_ERR_SHAPE, SR_ERR_OOM, SR_ERR_HIP, SR_ERR_COMM, SR_ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6
 PAD_MODES = {"mirror": 0, "replicate": 1, "reflect": 2, "constant": 3}
-WEIGHT_TYPES = {"linear": 0, "cosine": 1, "sigmoid": 2}
+WEIGHT_TYPES = {"linear": 0, "cosine": 1, "sigmoid": 2, "ones": 3}
 SSIM_MODES = {"uniform": 0, "gauss": 1, "simple": 2}
 SR_U8, SR_F32 = 0, 1
 
@@ -121,6 +121,9 @@ SIGNATURES = {
     "sr_rgb2gray_u8": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _i64]),
     "sr_resize_cubic_u8": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _i64, _i, _i]),
     "sr_resize_cubic_window_u8": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64]),
+    "sr_gray_moments_u8": (_i, [_vp, _vp, _i, _i64, _i64, _i, _i, _i, _i, C.POINTER(C.c_uint64)]),
+    "sr_histogram_u8": (_i, [_vp, _vp, _i64, _i, _i, _i, C.POINTER(C.c_uint64)]),
+    "sr_color_correct_u8": (_i, [_vp, _vp, _i64, _i, _i, _i, C.POINTER(C.c_float), _i, _i, C.c_float, _vp, _i64]),
     "sr_lpips_create": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), _i, C.POINTER(_vp), _i, _vp, _vp, C.POINTER(_vp)]),
     "sr_lpips_destroy": (_i, [_vp]),
     "sr_lpips_layer_sizes": (_i, [_i, _i, _i, _pi]),
@@ -306,6 +309,8 @@ class Context:
             check(self.lib.sr_ctx_create_on_stream(int(device), C.c_void_p(stream), C.byref(h)))
         self.handle = h
         self.device = int(device)
+        self.h2d_bytes = 0               # bytes moved by upload() / download() (transfer accounting for the tests and
+        self.d2h_bytes = 0               # the device-resident pipeline's "one upload, one download" claim)
 
     def close(self):
         if getattr(self, "handle", None):
@@ -329,11 +334,13 @@ class Context:
         arr = np.ascontiguousarray(arr)
         buf = DeviceBuffer(self, arr.nbytes)
         check(self.lib.sr_memcpy_h2d(self.handle, C.c_void_p(buf.ptr), arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+        self.h2d_bytes += arr.nbytes
         return buf
 
     def download(self, ptr: int, shape, dtype) -> np.ndarray:
         out = np.empty(shape, dtype=dtype)
         check(self.lib.sr_memcpy_d2h(self.handle, out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), out.nbytes))
+        self.d2h_bytes += out.nbytes
         return out
 
     def memset(self, ptr: int, value: int, nbytes: int):
@@ -449,6 +456,31 @@ class Context:
         return {"sse": out.sse, "ssim_uniform": out.ssim_uniform, "ssim_gauss": out.ssim_gauss,
                 "ssim_simple": out.ssim_simple}
 
+    def gray_std_u8(self, d_tiles, n, tile_bytes, stride, h, w, gray_shift=15, swap_rb=True) -> np.ndarray:
+        """np.std of the u8 gray image of n RGB tiles in HBM (from exact integer moments, float64)."""
+        sums = np.zeros(2 * max(n, 1), dtype=np.uint64)
+        check(self.lib.sr_gray_moments_u8(self.handle, C.c_void_p(d_tiles), int(n), int(tile_bytes), int(stride), int(h),
+                                          int(w), int(gray_shift), 1 if swap_rb else 0,
+                                          sums.ctypes.data_as(C.POINTER(C.c_uint64))))
+        cnt = float(h) * float(w)
+        s1, s2 = sums[0:2 * n:2].astype(np.float64), sums[1:2 * n:2].astype(np.float64)
+        m = s1 / cnt
+        return np.sqrt(np.maximum(s2 / cnt - m * m, 0.0))
+
+    def histogram_u8(self, d_img, stride, h, w, cn) -> np.ndarray:
+        """-> (cn, 256) int64 counts, np.histogram(channel, 256, [0, 256]) of u8 data."""
+        out = np.zeros((cn, 256), dtype=np.uint64)
+        check(self.lib.sr_histogram_u8(self.handle, C.c_void_p(d_img), int(stride), int(h), int(w), int(cn),
+                                       out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out.astype(np.int64)
+
+    def color_correct_u8(self, d_img, stride, h, w, cn, glut: np.ndarray, local_filter: bool, radius: int, eps: float,
+                         d_out, out_stride):
+        g = np.ascontiguousarray(glut, dtype=np.float32).reshape(cn, 256)
+        check(self.lib.sr_color_correct_u8(self.handle, C.c_void_p(d_img), int(stride), int(h), int(w), int(cn),
+                                           g.ctypes.data_as(C.POINTER(C.c_float)), 1 if local_filter else 0, int(radius),
+                                           C.c_float(eps), C.c_void_p(d_out), int(out_stride)))
+
     def rgb2gray_u8(self, d_rgb, stride, h, w, d_gray, gray_stride, gray_shift=15):
         check(self.lib.sr_rgb2gray_u8(self.handle, C.c_void_p(d_rgb), stride, h, w, gray_shift, C.c_void_p(d_gray),
                                       gray_stride))
@@ -503,6 +535,8 @@ class Context:
         is_u8 = all(t.dtype == np.uint8 for t in tiles)
         arrs = [np.ascontiguousarray(t if is_u8 else t.astype(np.float32)) for t in tiles]
         cn = arrs[0].shape[2] if arrs[0].ndim == 3 else 1
+        if any(a.ndim != arrs[0].ndim or a.shape[2:] != arrs[0].shape[2:] for a in arrs):
+            raise ValueError("fusion: every tile must have the same number of channels")   # the C side copies h*w*cn per tile
         H, W = int(output_shape[0]), int(output_shape[1])
         rects = (TileRect * n)(*[TileRect(int(p[1]), int(p[0]), a.shape[1], a.shape[0])
                                  for a, p in zip(arrs, positions_yx)])
@@ -511,6 +545,8 @@ class Context:
         outf = np.empty(out.shape, dtype=np.float32) if return_float else None
         fptr = outf.ctypes.data_as(C.c_void_p) if outf is not None else None
         dt = SR_U8 if is_u8 else SR_F32
+        self.h2d_bytes += sum(a.nbytes for a in arrs)        # the *_host entry points stage tiles and canvas themselves
+        self.d2h_bytes += out.nbytes + (outf.nbytes if outf is not None else 0)
         if laplacian:
             check(self.lib.sr_laplacian_fusion_host(self.handle, dt, ptrs, rects, n, cn, H, W, int(levels),
                                                     WEIGHT_TYPES[weight_type], out.ctypes.data_as(C.c_void_p), fptr))

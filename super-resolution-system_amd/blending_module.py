@@ -6,9 +6,9 @@ blend hot path (reference blending_module.py:38-56,96-136,164-363,369-561,661-76
 (include/sr_hip.h) -- there is no NumPy/OpenCV compute path here and no CPU fallback: without
 libsrhip.so or a GPU the compute methods raise.
 
-Out of scope for this path: Poisson / gradient-domain fusion, seam repair, colour
-correction, feather_blend's distance transform.  detect_seams is built.  Those methods exist so callers get a clear
-NotImplementedError instead of an AttributeError.
+Out of scope for this path: Poisson / gradient-domain fusion and seam repair -- those methods exist
+so callers get a clear NotImplementedError instead of an AttributeError.  Built from SURVEY 8(f): detect_seams (rank 1),
+multi_band_fusion, feather_blend and color_correction (rank 4).
 
 Reference quirks kept: bare arrays without output_shape fail like the
 reference (ValueError: max() of an empty sequence); the canvas perimeter, where every tile's cosine
@@ -179,8 +179,30 @@ class BlendingModule:
         ndims = {im.ndim for im in images}
         if ndims - {2, 3} or len(ndims) != 1:
             raise ValueError("tiles must all be HxW or all HxWxC arrays")
+        if len({im.shape[2:] for im in images}) != 1:
+            # the reference's accumulate raises NumPy's broadcast ValueError for e.g. RGB next to RGBA tiles
+            raise ValueError(f"tiles have different channel counts: {sorted({im.shape[2:] for im in images})}")
         return self._ctx().fusion_np(images, positions, output_shape, self.num_levels, weight_name,
                                      laplacian=laplacian)
+
+    def fuse_device(self, d_tiles: Sequence[int], strides: Sequence[int], rects_xywh, output_shape: Tuple[int, int],
+                    cn: int = 3, weight_type: Union[WeightType, str] = WeightType.COSINE, laplacian: bool = True):
+        """laplacian_fusion / weighted_average_fusion on u8 tiles that already live in HBM (device addresses, row
+        strides in bytes, canvas rectangles (x, y, w, h)) -> the u8 canvas as a device buffer the caller frees.  The
+        device-resident pipeline's stage 3: nothing crosses PCIe."""
+        ctx = self._ctx()
+        H, W = int(output_shape[0]), int(output_shape[1])
+        plan = _native.BlendPlan(ctx, rects_xywh, cn, H, W, self.num_levels if laplacian else 1, _weight_name(weight_type))
+        canvas = ctx.alloc(H * W * cn)
+        try:
+            plan.blend(d_tiles, strides, canvas.ptr, W * cn, laplacian=laplacian)
+            ctx.sync()
+        except Exception:
+            canvas.free()
+            raise
+        finally:
+            plan.close()
+        return canvas
 
     # -- fusions ----------------------------------------------------------------------------------
     def laplacian_fusion(self, tiles: List[Union[np.ndarray, TileInfo]],
@@ -255,8 +277,16 @@ class BlendingModule:
     def poisson_fusion(self, *a, **k):
         self._out_of_scope("poisson_fusion")
 
-    def feather_blend(self, *a, **k):
-        self._out_of_scope("feather_blend")
+    def feather_blend(self, tiles: List[Union[np.ndarray, TileInfo]], feather_width: int = 50,
+                      output_shape: Optional[Tuple[int, int]] = None) -> np.ndarray:
+        """blending_module.py:1272-1375.  The reference weights every tile by the cosine of
+        cv2.distanceTransform(all-ones mask) / max: a mask without a zero pixel has no distance to measure, every value
+        saturates at the transform's DIST_MAX, the normalised distance is 1 and the weight is 1 everywhere -- so this is
+        the plain per-pixel average of the covering tiles (``feather_width`` is unused there too).  Runs as the weighted
+        gather with unit weights (SR_W_ONES); the chamfer transform itself is restated in the test oracle."""
+        del feather_width
+        images, positions, shape = self._collect(tiles, output_shape, guess_without_shape=True)
+        return self._fuse(images, positions, shape, "ones", laplacian=False)
 
     def gradient_domain_fusion(self, *a, **k):
         self._out_of_scope("gradient_domain_fusion")
@@ -324,8 +354,70 @@ class BlendingModule:
     def repair_seams(self, *a, **k):
         self._out_of_scope("repair_seams")
 
-    def color_correction(self, *a, **k):
-        self._out_of_scope("color_correction")
+    # -- colour consistency (blending_module.py:969-1146) ---------------------------------------------------------
+    @staticmethod
+    def _histogram_lut(src_hist: np.ndarray, ref_hist: np.ndarray) -> np.ndarray:
+        """_histogram_matching's 256-entry table of one channel (:1045-1059): float64 CDFs scaled to 255, entry i = first
+        index of the reference CDF closest to src_cdf[i]."""
+        src_cdf = np.asarray(src_hist).cumsum()
+        ref_cdf = np.asarray(ref_hist).cumsum()
+        src_cdf = (src_cdf / src_cdf[-1]) * 255
+        ref_cdf = (ref_cdf / ref_cdf[-1]) * 255
+        return np.argmin(np.abs(ref_cdf[None, :] - src_cdf[:, None]), axis=1).astype(np.uint8)
+
+    @staticmethod
+    def _mean_std_table(src_hist: np.ndarray, ref_hist: np.ndarray) -> np.ndarray:
+        """_mean_std_matching (:1062-1086) of one channel evaluated for the 256 possible source values: float32
+        (v - src_mean) * (ref_std / (src_std + 1e-6)) + ref_mean, the moments taken exactly from the histograms."""
+        v = np.arange(256, dtype=np.float64)
+
+        def moments(hist):
+            hist = np.asarray(hist, dtype=np.float64)
+            n = hist.sum()
+            m = (hist * v).sum() / n
+            return np.float32(m), np.float32(np.sqrt(max((hist * v * v).sum() / n - m * m, 0.0)))
+
+        sm, ss = moments(src_hist)
+        rm, rs = moments(ref_hist)
+        gain = np.float32(rs / np.float32(ss + np.float32(1e-6)))
+        return (np.arange(256, dtype=np.float32) - sm) * gain + rm
+
+    def color_correction(self, image: np.ndarray, reference_tile: np.ndarray, method: str = "histogram",
+                         local_filter: bool = True) -> np.ndarray:
+        """Match the image's colours to a reference tile (:969-1017): per-channel histogram matching or mean / std
+        matching, then the local guided filter (radius 8, eps 0.01; the _simple_guided_filter branch).  Histograms,
+        the per-pixel mapping and the box-filter passes run on the GPU; the 256-entry tables are built here."""
+        if method == "none":
+            return image
+        img = np.ascontiguousarray(image)
+        ref = np.ascontiguousarray(reference_tile)
+        if img.dtype != np.uint8 or ref.dtype != np.uint8:
+            raise NotImplementedError("color_correction: uint8 images only on the HIP path")
+        cn = img.shape[2] if img.ndim == 3 else 1
+        rcn = ref.shape[2] if ref.ndim == 3 else 1
+        if cn != rcn or cn > 4:
+            raise ValueError(f"color_correction: channel layouts {img.shape} vs {ref.shape}")
+        ctx = self._ctx()
+        d_img, d_ref = ctx.upload(img), ctx.upload(ref)
+        out = ctx.alloc(img.size)
+        try:
+            h, w = img.shape[:2]
+            sh = ctx.histogram_u8(d_img.ptr, w * cn, h, w, cn)
+            rh = ctx.histogram_u8(d_ref.ptr, ref.shape[1] * cn, ref.shape[0], ref.shape[1], cn)
+            glut = np.empty((cn, 256), dtype=np.float32)
+            for c in range(cn):
+                if method == "histogram":
+                    glut[c] = self._histogram_lut(sh[c], rh[c]).astype(np.float32)
+                elif method == "mean_std":
+                    glut[c] = self._mean_std_table(sh[c], rh[c])
+                else:
+                    glut[c] = np.arange(256, dtype=np.float32)
+            ctx.color_correct_u8(d_img.ptr, w * cn, h, w, cn, glut, bool(local_filter), 8, 0.01, out.ptr, w * cn)
+            return ctx.download(out.ptr, img.shape, np.uint8)
+        finally:
+            ctx.sync()
+            for b in (d_img, d_ref, out):
+                b.free()
 
 
 def create_tile_grid(images: List[np.ndarray], grid_shape: Tuple[int, int],

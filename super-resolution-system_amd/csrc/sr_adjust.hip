@@ -1,1 +1,314 @@
-// placeholder
+// sr_adjust.hip -- BlendingModule.color_correction (blending_module.py:969-1146) on gfx950.
+//
+//   _histogram_matching : per-channel 256-bin histograms on the GPU (LDS bins per block, one atomic per bin per block);
+//                         the CDF / argmin table is 256-entry host bookkeeping (Python mirror) and comes back as a table.
+//   _mean_std_matching  : the affine map evaluated per source value -> the same kind of table.
+//   _simple_guided_filter(guide = corrected, src = image): five cv2.blur box means and fp32 element-wise algebra, as two
+//                         passes: k_cc_coeff (box means of g, s, g*s, g*g -> a, b) and k_cc_apply (box means of a, b ->
+//                         mean_a * g + mean_b -> clip -> truncate).  Box sums are accumulated in fp64 like cv::boxFilter
+//                         does for CV_32F data (sum type CV_64F) in a fixed order: each window row left to right, then the
+//                         row sums top to bottom; mean = (float)(sum * (1.0 / (r * r))).  Separable through LDS: a block
+//                         owns 64 x 16 output pixels of one channel at a time.
+// Everything is HBM-bound byte / fp32 work (3 B in, 24 B of a / b out and back in, 3 B out per pixel); no MFMA.
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "sr_ctx.h"
+
+namespace {
+
+__device__ __forceinline__ int cc_reflect101(int p, int n)
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
+    return p;
+}
+
+__global__ __launch_bounds__(256) void k_hist_u8(const unsigned char *__restrict__ img, long long stride, int h, int w, int cn,
+                                                 unsigned long long *__restrict__ hist)
+{
+    __shared__ unsigned bins[4][256];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 4 * 256; i += 256) (&bins[0][0])[i] = 0u;
+    __syncthreads();
+    const long long rowlen = (long long)w * cn;
+    for (int y = blockIdx.y; y < h; y += gridDim.y) {
+        const unsigned char *row = img + (size_t)y * stride;
+        for (long long i = (long long)blockIdx.x * 256 + tid; i < rowlen; i += (long long)gridDim.x * 256)
+            atomicAdd(&bins[(int)(i % cn)][row[i]], 1u);
+    }
+    __syncthreads();
+    for (int i = tid; i < cn * 256; i += 256) {
+        const unsigned v = (&bins[0][0])[i];
+        if (v) atomicAdd(&hist[i], (unsigned long long)v);
+    }
+}
+
+// TilingModule.split_image's complexity_score = np.std(cv2.cvtColor(tile, COLOR_BGR2GRAY)) (tiling_module.py:746-749: the
+// BGR constants applied to RGB data, i.e. R and B weights swapped): exact integer sums of g and g^2 per tile.
+__global__ __launch_bounds__(256) void k_gray_moments(const unsigned char *__restrict__ tiles, long long tile_bytes,
+                                                      long long stride, int h, int w, int shift, int swap_rb,
+                                                      unsigned long long *__restrict__ sums)
+{
+    const unsigned char *base = tiles + (size_t)blockIdx.z * tile_bytes;
+    unsigned long long s1 = 0, s2 = 0;
+    for (int y = blockIdx.y; y < h; y += gridDim.y) {
+        const unsigned char *row = base + (size_t)y * stride;
+        for (int x = blockIdx.x * 256 + threadIdx.x; x < w; x += gridDim.x * 256) {
+            const int c0 = row[3 * x], c1 = row[3 * x + 1], c2 = row[3 * x + 2];
+            const int r = swap_rb ? c2 : c0, b = swap_rb ? c0 : c2;
+            const int g = shift == 15 ? (r * 9798 + c1 * 19235 + b * 3735 + (1 << 14)) >> 15
+                                      : (r * 4899 + c1 * 9617 + b * 1868 + (1 << 13)) >> 14;
+            s1 += (unsigned)g;
+            s2 += (unsigned)(g * g);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_down(s1, o, 64);
+        s2 += __shfl_down(s2, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&sums[2 * blockIdx.z], s1);
+        atomicAdd(&sums[2 * blockIdx.z + 1], s2);
+    }
+}
+
+#define CC_TW 64
+#define CC_TH 16
+
+// pass 1: a = cov(g, s) / (var(g) + eps), b = mean_s - a * mean_g per pixel and channel (fp32 HWC planes a, b)
+__global__ __launch_bounds__(256) void k_cc_coeff(const unsigned char *__restrict__ img, long long stride, int h, int w, int cn,
+                                                  const float *__restrict__ glut, int R, float eps, double scale,
+                                                  float *__restrict__ a_out, float *__restrict__ b_out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int PH = CC_TH + R - 1, PW = CC_TW + R - 1, anchor = R / 2;
+    float *g_p = (float *)smem;                               // [PH][PW]
+    float *s_p = g_p + PH * PW;
+    double *hs = (double *)(smem + (((size_t)2 * PH * PW * sizeof(float) + 15) & ~(size_t)15));   // [PH][TW][4]
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * CC_TW, y0 = blockIdx.y * CC_TH;
+    for (int c = 0; c < cn; ++c) {
+        for (int e = tid; e < PH * PW; e += 256) {
+            const int py = e / PW, px = e - py * PW;
+            const int gy = cc_reflect101(y0 + py - anchor, h), gx = cc_reflect101(x0 + px - anchor, w);
+            const int v = img[(size_t)gy * stride + (size_t)gx * cn + c];
+            g_p[e] = glut[c * 256 + v];
+            s_p[e] = (float)v;
+        }
+        __syncthreads();
+        for (int e = tid; e < PH * CC_TW; e += 256) {
+            const int py = e / CC_TW, ox = e - py * CC_TW;
+            double sg = 0.0, ss = 0.0, sgs = 0.0, sgg = 0.0;
+            for (int k = 0; k < R; ++k) {
+                const float g = g_p[py * PW + ox + k], s = s_p[py * PW + ox + k];
+                sg += (double)g;
+                ss += (double)s;
+                sgs += (double)(g * s);
+                sgg += (double)(g * g);
+            }
+            double *o = hs + (size_t)e * 4;
+            o[0] = sg; o[1] = ss; o[2] = sgs; o[3] = sgg;
+        }
+        __syncthreads();
+        for (int e = tid; e < CC_TH * CC_TW; e += 256) {
+            const int oy = e / CC_TW, ox = e - oy * CC_TW;
+            const int y = y0 + oy, x = x0 + ox;
+            if (y >= h || x >= w) continue;
+            double t[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int k = 0; k < R; ++k) {
+                const double *r = hs + ((size_t)(oy + k) * CC_TW + ox) * 4;
+                t[0] += r[0]; t[1] += r[1]; t[2] += r[2]; t[3] += r[3];
+            }
+            const float mg = (float)(t[0] * scale), ms = (float)(t[1] * scale);
+            const float mgs = (float)(t[2] * scale), mgg = (float)(t[3] * scale);
+            const float cov = mgs - mg * ms, var = mgg - mg * mg;
+            const float a = cov / (var + eps);
+            const float b = ms - a * mg;
+            const size_t o = ((size_t)y * w + x) * cn + c;
+            a_out[o] = a;
+            b_out[o] = b;
+        }
+        __syncthreads();
+    }
+}
+
+// pass 2: out = u8(clip(mean_a * g + mean_b, 0, 255))
+__global__ __launch_bounds__(256) void k_cc_apply(const unsigned char *__restrict__ img, long long stride, int h, int w, int cn,
+                                                  const float *__restrict__ glut, int R, double scale,
+                                                  const float *__restrict__ a_in, const float *__restrict__ b_in,
+                                                  unsigned char *__restrict__ out, long long ostride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int PH = CC_TH + R - 1, PW = CC_TW + R - 1, anchor = R / 2;
+    float *a_p = (float *)smem;
+    float *b_p = a_p + PH * PW;
+    double *hs = (double *)(smem + (((size_t)2 * PH * PW * sizeof(float) + 15) & ~(size_t)15));   // [PH][TW][2]
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * CC_TW, y0 = blockIdx.y * CC_TH;
+    for (int c = 0; c < cn; ++c) {
+        for (int e = tid; e < PH * PW; e += 256) {
+            const int py = e / PW, px = e - py * PW;
+            const int gy = cc_reflect101(y0 + py - anchor, h), gx = cc_reflect101(x0 + px - anchor, w);
+            const size_t o = ((size_t)gy * w + gx) * cn + c;
+            a_p[e] = a_in[o];
+            b_p[e] = b_in[o];
+        }
+        __syncthreads();
+        for (int e = tid; e < PH * CC_TW; e += 256) {
+            const int py = e / CC_TW, ox = e - py * CC_TW;
+            double sa = 0.0, sb = 0.0;
+            for (int k = 0; k < R; ++k) {
+                sa += (double)a_p[py * PW + ox + k];
+                sb += (double)b_p[py * PW + ox + k];
+            }
+            hs[(size_t)e * 2] = sa;
+            hs[(size_t)e * 2 + 1] = sb;
+        }
+        __syncthreads();
+        for (int e = tid; e < CC_TH * CC_TW; e += 256) {
+            const int oy = e / CC_TW, ox = e - oy * CC_TW;
+            const int y = y0 + oy, x = x0 + ox;
+            if (y >= h || x >= w) continue;
+            double ta = 0.0, tb = 0.0;
+            for (int k = 0; k < R; ++k) {
+                ta += hs[((size_t)(oy + k) * CC_TW + ox) * 2];
+                tb += hs[((size_t)(oy + k) * CC_TW + ox) * 2 + 1];
+            }
+            const float ma = (float)(ta * scale), mb = (float)(tb * scale);
+            const float g = glut[c * 256 + img[(size_t)y * stride + (size_t)x * cn + c]];
+            const float r = ma * g + mb;
+            const float cl = r < 0.0f ? 0.0f : (r > 255.0f ? 255.0f : r);
+            out[(size_t)y * ostride + (size_t)x * cn + c] = (unsigned char)cl;
+        }
+        __syncthreads();
+    }
+}
+
+// no local filter: out = u8(clip(glut[c][v], 0, 255))
+__global__ __launch_bounds__(256) void k_cc_map(const unsigned char *__restrict__ img, long long stride, int h, long long rowlen,
+                                                int cn, const float *__restrict__ glut, unsigned char *__restrict__ out,
+                                                long long ostride)
+{
+    __shared__ unsigned char tab[4 * 256];
+    for (int i = threadIdx.x; i < cn * 256; i += 256) {
+        const float r = glut[i];
+        const float cl = r < 0.0f ? 0.0f : (r > 255.0f ? 255.0f : r);
+        tab[i] = (unsigned char)cl;
+    }
+    __syncthreads();
+    for (int y = blockIdx.y; y < h; y += gridDim.y)
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < rowlen; i += (long long)gridDim.x * 256)
+            out[(size_t)y * ostride + i] = tab[(int)(i % cn) * 256 + img[(size_t)y * stride + i]];
+}
+
+}  // namespace
+
+extern "C" {
+
+int sr_histogram_u8(sr_ctx *ctx, const uint8_t *d_img, int64_t stride, int h, int w, int cn, uint64_t *h_hist)
+{
+    CTX_ENTER(ctx);
+    if (!d_img || !h_hist || h < 1 || w < 1 || cn < 1 || cn > 4) return sr_set_error(SR_ERR_INVALID_ARG, "sr_histogram_u8: bad arguments");
+    if (stride < (int64_t)w * cn) return sr_set_error(SR_ERR_SHAPE, "sr_histogram_u8: stride smaller than a row");
+    void *scr = nullptr;
+    int rc = ctx_scratch(ctx, 4 * 256 * sizeof(unsigned long long), &scr);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(scr, 0, 4 * 256 * sizeof(unsigned long long), ctx->stream));
+    {
+        ProfScope ps(ctx, "histogram");
+        const long long rowlen = (long long)w * cn;
+        dim3 grid((unsigned)std::min<long long>((rowlen + 255) / 256, 32), (unsigned)std::min(h, 512));
+        hipLaunchKernelGGL(k_hist_u8, grid, dim3(256), 0, ctx->stream, d_img, (long long)stride, h, w, cn, (unsigned long long *)scr);
+    }
+    rc = check_launch("histogram");
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(h_hist, scr, (size_t)cn * 256 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(stream_sync(ctx));
+    return SR_OK;
+}
+
+int sr_gray_moments_u8(sr_ctx *ctx, const uint8_t *d_tiles, int n, int64_t tile_bytes, int64_t stride, int h, int w,
+                       int gray_shift, int swap_rb, uint64_t *h_sums)
+{
+    CTX_ENTER(ctx);
+    if (!d_tiles || !h_sums || n < 0 || h < 1 || w < 1 || (gray_shift != 14 && gray_shift != 15))
+        return sr_set_error(SR_ERR_INVALID_ARG, "sr_gray_moments_u8: bad arguments");
+    if (stride < (int64_t)w * 3) return sr_set_error(SR_ERR_SHAPE, "sr_gray_moments_u8: stride smaller than a row");
+    if (n == 0) return SR_OK;
+    void *scr = nullptr;
+    int rc = ctx_scratch(ctx, (size_t)n * 2 * sizeof(unsigned long long), &scr);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(scr, 0, (size_t)n * 2 * sizeof(unsigned long long), ctx->stream));
+    {
+        ProfScope ps(ctx, "gray_moments");
+        dim3 grid((unsigned)std::min((w + 255) / 256, 8), (unsigned)std::min(h, 64), (unsigned)n);
+        hipLaunchKernelGGL(k_gray_moments, grid, dim3(256), 0, ctx->stream, d_tiles, (long long)tile_bytes, (long long)stride, h, w,
+                           gray_shift, swap_rb ? 1 : 0, (unsigned long long *)scr);
+    }
+    rc = check_launch("gray_moments");
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(h_sums, scr, (size_t)n * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(stream_sync(ctx));
+    return SR_OK;
+}
+
+int sr_color_correct_u8(sr_ctx *ctx, const uint8_t *d_img, int64_t stride, int h, int w, int cn, const float *h_glut,
+                        int local_filter, int radius, float eps, uint8_t *d_out, int64_t out_stride)
+{
+    CTX_ENTER(ctx);
+    if (!d_img || !h_glut || !d_out || h < 1 || w < 1 || cn < 1 || cn > 4) return sr_set_error(SR_ERR_INVALID_ARG, "sr_color_correct_u8: bad arguments");
+    if (stride < (int64_t)w * cn || out_stride < (int64_t)w * cn) return sr_set_error(SR_ERR_SHAPE, "sr_color_correct_u8: stride smaller than a row");
+    if (local_filter && (radius < 1 || radius > 16)) return sr_set_error(SR_ERR_INVALID_ARG, "sr_color_correct_u8: radius must be 1..16");
+    const size_t npx = (size_t)h * w * cn;
+    const size_t tab_bytes = 4 * 256 * sizeof(float);
+    void *scr = nullptr;
+    int rc = ctx_scratch(ctx, tab_bytes + 256, &scr);
+    if (rc) return rc;
+    float *d_glut = (float *)scr;
+    HIPCHK(upload_small(ctx, d_glut, h_glut, (size_t)cn * 256 * sizeof(float)));
+    if (!local_filter) {
+        ProfScope ps(ctx, "color_map");
+        const long long rowlen = (long long)w * cn;
+        dim3 grid((unsigned)std::min<long long>((rowlen + 255) / 256, 64), (unsigned)std::min(h, 1024));
+        hipLaunchKernelGGL(k_cc_map, grid, dim3(256), 0, ctx->stream, d_img, (long long)stride, h, rowlen, cn, (const float *)d_glut,
+                           d_out, (long long)out_stride);
+        return check_launch("color_map");
+    }
+    // a / b planes (8 bytes per sample): an allocation of their own, released when the call is done
+    float *d_a = nullptr;
+    {
+        hipError_t e = hipMalloc((void **)&d_a, 2 * npx * sizeof(float));
+        if (e != hipSuccess)
+            return sr_set_error(e == hipErrorOutOfMemory ? SR_ERR_OOM : SR_ERR_HIP, "sr_color_correct_u8: %s", hipGetErrorString(e));
+    }
+    float *d_b = d_a + npx;
+    const int PH = CC_TH + radius - 1, PW = CC_TW + radius - 1;
+    const size_t patch = (((size_t)2 * PH * PW * sizeof(float)) + 15) & ~(size_t)15;
+    const size_t lds1 = patch + (size_t)PH * CC_TW * 4 * sizeof(double), lds2 = patch + (size_t)PH * CC_TW * 2 * sizeof(double);
+    const double scale = 1.0 / ((double)radius * (double)radius);
+    const dim3 grid((w + CC_TW - 1) / CC_TW, (h + CC_TH - 1) / CC_TH);
+    if (lds1 > 48 * 1024) {
+        (void)hipFuncSetAttribute((const void *)k_cc_coeff, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        (void)hipFuncSetAttribute((const void *)k_cc_apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    }
+    {
+        ProfScope ps(ctx, "guided_coeff");
+        hipLaunchKernelGGL(k_cc_coeff, grid, dim3(256), lds1, ctx->stream, d_img, (long long)stride, h, w, cn, (const float *)d_glut,
+                           radius, eps, scale, d_a, d_b);
+    }
+    {
+        ProfScope ps(ctx, "guided_apply");
+        hipLaunchKernelGGL(k_cc_apply, grid, dim3(256), lds2, ctx->stream, d_img, (long long)stride, h, w, cn, (const float *)d_glut,
+                           radius, scale, (const float *)d_a, (const float *)d_b, d_out, (long long)out_stride);
+    }
+    rc = check_launch("color_correct");
+    hipError_t es = stream_sync(ctx);
+    (void)hipFree(d_a);
+    if (rc) return rc;
+    if (es != hipSuccess) return sr_set_error(SR_ERR_HIP, "sr_color_correct_u8: %s", hipGetErrorString(es));
+    return SR_OK;
+}
+
+}  // extern "C"

@@ -2582,7 +2582,7 @@ int sr_blend_plan_create(sr_ctx *ctx, const sr_tile_rect *h_tiles, int n, int cn
     if (cn < 1 || cn > 4) return sr_set_error(SR_ERR_INVALID_ARG, "sr_blend_plan_create: channels must be 1..4");
     if (canvas_h < 1 || canvas_w < 1) return sr_set_error(SR_ERR_SHAPE, "sr_blend_plan_create: empty canvas");
     if (levels < 1) return sr_set_error(SR_ERR_INVALID_ARG, "sr_blend_plan_create: levels must be >= 1");
-    if (weight_type < 0 || weight_type > 2) return sr_set_error(SR_ERR_INVALID_ARG, "sr_blend_plan_create: bad weight type");
+    if (weight_type < 0 || weight_type > SR_W_ONES) return sr_set_error(SR_ERR_INVALID_ARG, "sr_blend_plan_create: bad weight type");
     row_begin = std::max(row_begin, 0);
     row_end = std::min(row_end, canvas_h);
     if (row_begin > row_end) row_begin = row_end;
@@ -2610,7 +2610,7 @@ int sr_blend_plan_create(sr_ctx *ctx, const sr_tile_rect *h_tiles, int n, int cn
             return sr_set_error(SR_ERR_INVALID_ARG, "sr_blend_plan_create: tile %d has bad rectangle (%d,%d,%d,%d)", t, r.x,
                                 r.y, r.w, r.h);
         }
-        if (std::min(r.w, r.h) < 8) {
+        if (std::min(r.w, r.h) < 8 && weight_type != SR_W_ONES) {
             delete P;
             return sr_set_error(SR_ERR_INVALID_ARG,
                                 "sr_blend_plan_create: tile %d is %dx%d; min side < 8 gives the reference a zero "
@@ -2624,7 +2624,7 @@ int sr_blend_plan_create(sr_ctx *ctx, const sr_tile_rect *h_tiles, int n, int cn
         T.x = r.x;
         T.y = r.y;
         T.nl = lv[t].nl;
-        T.fw = std::min(r.w, r.h) / 8;
+        T.fw = std::max(std::min(r.w, r.h) / 8, 1);
         P->max_nl = std::max(P->max_nl, T.nl);
         auto key = std::make_pair(r.h, r.w);
         auto it = cls_of.find(key);

@@ -126,7 +126,8 @@ int sr_weight_lut(int fw, int weight_type, float *h_lut)
         double nd = (double)d / (double)fw;
         nd = std::min(1.0, std::max(0.0, nd));
         double v;
-        if (weight_type == SR_W_COSINE) v = 0.5 * (1 - std::cos(M_PI * nd));
+        if (weight_type == SR_W_ONES) v = 1.0;
+        else if (weight_type == SR_W_COSINE) v = 0.5 * (1 - std::cos(M_PI * nd));
         else if (weight_type == SR_W_SIGMOID) v = 1 / (1 + std::exp(-10 * (nd - 0.5)));
         else v = nd;
         h_lut[d] = (float)v;

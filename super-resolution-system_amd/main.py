@@ -53,6 +53,8 @@ class PipelineConfig:
     volc_sk: str = ""
     volc_region: str = "cn-beijing"
     sr_scale: int = 2          # the reference hard-codes 2 (main.py:217,322)
+    device_resident: bool = True   # with the built-in SR stub: source uploaded once, every stage on device pointers,
+                                   # only the canvas comes back for the writer (a custom sr_backend gets host arrays)
 
 
 @dataclass
@@ -126,9 +128,81 @@ class SuperResolutionPipeline:
 
         return list(await asyncio.gather(*[limited(t) for t in tiles]))
 
+    def _write_outputs(self, fused: np.ndarray, output_path: str, report: Optional[Dict[str, Any]]):
+        """Stage 5 (main.py:399-410): TIFF-LZW / PNG (compress_level 3) / JPEG-95 by extension + the QA report JSON."""
+        from PIL import Image
+        Path(output_path).parent.mkdir(parents=True, exist_ok=True)
+        img = Image.fromarray(fused)
+        low = output_path.lower()
+        if low.endswith('.tiff') or low.endswith('.tif'):
+            img.save(output_path, format='TIFF', compression='tiff_lzw')
+        elif low.endswith('.png'):
+            img.save(output_path, format='PNG', compress_level=3)
+        else:
+            img.save(output_path, quality=95)
+        if report:
+            with open(output_path.rsplit('.', 1)[0] + '_qa_report.json', 'w', encoding='utf-8') as f:
+                json.dump(report, f, indent=2, ensure_ascii=False, default=str)
+
+    async def _process_device(self, input_path: str, output_path: str, roi_regions, start: float) -> PipelineResult:
+        """The five stages with the data resident in HBM (main.py:293-410 order): the decoded source goes up once
+        (the only large H2D), tiles are cut and padded, the bicubic SR stand-in runs per tile, the tiles are fused and
+        the canvas assessed against the source -- all on device addresses -- and only the finished canvas comes down
+        (the only large D2H) for the writer.  Same arithmetic as the host-array path, so the same results."""
+        from tiling_module import _load_rgb
+        tm, s = self.tiling_module, self.config.sr_scale
+        self.transfers = None
+        original = _load_rgb(input_path)
+        ih, iw = original.shape[:2]
+        ctx = self.quality_module._ctx()
+        h2d0, d2h0 = ctx.h2d_bytes, ctx.d2h_bytes
+        # Stage 1: tiling (metadata on the host, pixels stay on the GPU)
+        tiles = tm.split_array(original, image_hash=tm._compute_image_hash(input_path), image_path=input_path,
+                               device_resident=True)
+        ts = tm.device_tiles
+        block, out_block = tm.block_size, tm.block_size * s
+        sr_bufs, canvas = [], None
+        try:
+            # Stage 2: SR stand-in, tile by tile, HBM -> HBM
+            for i in range(len(tiles)):
+                buf = ctx.alloc(out_block * out_block * 3)
+                sr_bufs.append(buf)
+                ctx.resize_cubic_u8(ts.tile_ptr(i), block * 3, block, block, 3, buf.ptr, out_block * 3, out_block, out_block)
+            # Stage 3: blending (the canvas is cropped to the un-padded image, scaled)
+            rects = [(t.metadata.global_x * s, t.metadata.global_y * s, out_block, out_block) for t in tiles]
+            H, W = ih * s, iw * s
+            canvas = self.blending_module.fuse_device([b.ptr for b in sr_bufs], [out_block * 3] * len(tiles), rects, (H, W), 3,
+                                                      laplacian=self.config.blend_method != 'weighted')
+            # Stage 4: quality assessment, source (still resident from stage 1) vs canvas
+            report, score = None, None
+            if self.config.enable_qa:
+                qa = self.quality_module.evaluate_full_reference_device(ts.d_img.ptr, (ih, iw, 3), canvas.ptr, (H, W, 3),
+                                                                        scale_factor=W / iw)
+                report = {'full_reference': qa,
+                          'commercial': self.quality_module.evaluate_commercial(None, roi_regions or []),
+                          'timestamp': datetime.now().isoformat()}
+                score = qa.get('overall_score', 0)
+            # Stage 5: the one download, then the writer
+            fused = ctx.download(canvas.ptr, (H, W, 3), np.uint8)
+        finally:
+            ctx.sync()
+            for b in sr_bufs + ([canvas] if canvas is not None else []):
+                b.free()
+            tm.release_device_tiles()
+        self.transfers = {"h2d_bytes": ctx.h2d_bytes - h2d0, "d2h_bytes": ctx.d2h_bytes - d2h0,
+                          "source_bytes": int(original.nbytes), "canvas_bytes": int(fused.nbytes)}
+        self._write_outputs(fused, output_path, report)
+        return PipelineResult(True, output_path, time.time() - start, len(tiles), len(tiles), 0, score, report, None)
+
     async def process(self, input_path: str, output_path: str, prompt: str = "",
                       roi_regions: Optional[List[Dict]] = None) -> PipelineResult:
         start = time.time()
+        if self.config.device_resident and self.sr_backend is bicubic_stub_backend:
+            try:
+                return await self._process_device(input_path, output_path, roi_regions, start)
+            except Exception as exc:  # noqa: BLE001 - the reference reports every failure in the result record
+                self.logger.error("Pipeline执行失败: %s", exc, exc_info=True)
+                return PipelineResult(False, None, time.time() - start, 0, 0, 0, None, None, str(exc))
         try:
             # Stage 1: tiling
             tiles = self.tiling_module.split_image(input_path)
@@ -165,18 +239,7 @@ class SuperResolutionPipeline:
                           'timestamp': datetime.now().isoformat()}
                 score = qa.get('overall_score', 0)
             # Stage 5: output
-            Path(output_path).parent.mkdir(parents=True, exist_ok=True)
-            img = Image.fromarray(fused)
-            low = output_path.lower()
-            if low.endswith('.tiff') or low.endswith('.tif'):
-                img.save(output_path, format='TIFF', compression='tiff_lzw')
-            elif low.endswith('.png'):
-                img.save(output_path, format='PNG', compress_level=3)
-            else:
-                img.save(output_path, quality=95)
-            if report:
-                with open(output_path.rsplit('.', 1)[0] + '_qa_report.json', 'w', encoding='utf-8') as f:
-                    json.dump(report, f, indent=2, ensure_ascii=False, default=str)
+            self._write_outputs(fused, output_path, report)
             return PipelineResult(True, output_path, time.time() - start, len(tiles), len(ok), failed, score, report, None)
         except Exception as exc:  # noqa: BLE001 - the reference reports every failure in the result record
             self.logger.error("Pipeline执行失败: %s", exc, exc_info=True)

@@ -73,11 +73,17 @@ class ScaleConfig:
 
 
 class _DevImage:
-    """A u8 image resident in HBM (dense HWC or HW)."""
+    """A u8 image resident in HBM (dense HWC or HW): uploaded from an array, freshly allocated, or a view of memory
+    somebody else owns (``ptr=``: the device-resident pipeline hands its source and canvas over this way)."""
 
-    def __init__(self, ctx, arr: Optional[np.ndarray] = None, shape=None):
+    def __init__(self, ctx, arr: Optional[np.ndarray] = None, shape=None, ptr: Optional[int] = None):
         self.ctx = ctx
-        if arr is not None:
+        self._ptr = None
+        if ptr is not None:
+            self.shape = tuple(shape)
+            self.buf = None
+            self._ptr = int(ptr)
+        elif arr is not None:
             arr = np.ascontiguousarray(arr, dtype=np.uint8)
             self.shape = arr.shape
             self.buf = ctx.upload(arr)
@@ -98,10 +104,11 @@ class _DevImage:
     def stride(self): return self.w * self.cn
 
     @property
-    def ptr(self): return self.buf.ptr
+    def ptr(self): return self._ptr if self.buf is None else self.buf.ptr
 
     def free(self):
-        self.buf.free()
+        if self.buf is not None:
+            self.buf.free()
 
 
 class QualityAssessmentModule:
@@ -301,6 +308,20 @@ class QualityAssessmentModule:
         o, u = self._pair(original, upscaled, "evaluate_full_reference")
         ctx = self._ctx()
         d_o, d_u = _DevImage(ctx, o), _DevImage(ctx, u)      # uploaded once, every metric reads HBM
+        return self._evaluate_full_reference_dev(d_o, d_u)
+
+    def evaluate_full_reference_device(self, d_original: int, original_shape, d_upscaled: int, upscaled_shape,
+                                       scale_factor: int = 4) -> Dict[str, float]:
+        """evaluate_full_reference on two dense u8 images that already live in HBM (device addresses + shapes): what
+        the device-resident pipeline calls -- nothing is uploaded, only the scalar sums come back."""
+        ctx = self._ctx()
+        if len(original_shape) != len(upscaled_shape) or (len(original_shape) == 3 and original_shape[2] != upscaled_shape[2]):
+            raise ValueError(f"evaluate_full_reference: images have different channel layouts {original_shape} vs {upscaled_shape}")
+        return self._evaluate_full_reference_dev(_DevImage(ctx, shape=original_shape, ptr=d_original),
+                                                 _DevImage(ctx, shape=upscaled_shape, ptr=d_upscaled))
+
+    def _evaluate_full_reference_dev(self, d_o: _DevImage, d_u: _DevImage) -> Dict[str, float]:
+        ctx = d_o.ctx
         try:
             metrics: Dict[str, Any] = {}
             metrics.update(self._downsample_comparison_dev(d_o, d_u))

@@ -151,6 +151,28 @@ class LRUCache:
             return list(self.cache.keys())
 
 
+class DeviceTileSet:
+    """What split_array(device_resident=True) leaves in HBM: the source image and its n padded block x block tiles."""
+
+    def __init__(self, ctx, d_img, d_tiles, n: int, block: int, image_h: int, image_w: int):
+        self.ctx, self.d_img, self.d_tiles = ctx, d_img, d_tiles
+        self.n, self.block, self.image_h, self.image_w = n, block, image_h, image_w
+
+    @property
+    def tile_bytes(self) -> int:
+        return self.block * self.block * 3
+
+    def tile_ptr(self, i: int) -> int:
+        return self.d_tiles.ptr + i * self.tile_bytes
+
+    def free(self):
+        self.ctx.sync()
+        for b in (self.d_img, self.d_tiles):
+            if b is not None:
+                b.free()
+        self.d_img = self.d_tiles = None
+
+
 def _load_rgb(image_path: str) -> np.ndarray:
     from PIL import Image
     try:
@@ -185,6 +207,7 @@ class TilingModule:
         self.registry_lock = threading.Lock()
         self.processing_state: Dict[str, dict] = {}
         self.device = device
+        self.device_tiles: Optional[DeviceTileSet] = None
         logger.info("TilingModule初始化完成: block_size=%s, overlap_ratio=%s, padding_mode=%s",
                     block_size, overlap_ratio, padding_mode)
 
@@ -237,8 +260,12 @@ class TilingModule:
                                 save_metadata=save_metadata, image_path=image_path)
 
     def split_array(self, image: np.ndarray, image_hash: str = "", save_metadata: bool = True,
-                    image_path: str = "") -> List[Tile]:
-        """split_image on an in-memory RGB u8 array (extension: the reference only takes a path)."""
+                    image_path: str = "", device_resident: bool = False) -> List[Tile]:
+        """split_image on an in-memory RGB u8 array (extension: the reference only takes a path).
+
+        ``device_resident=True`` (the pipeline's mode): the image is uploaded once and stays in HBM together with the
+        padded tiles (``self.device_tiles``); the returned tiles carry metadata only (``data is None``), the complexity
+        score comes from exact gray moments taken on the GPU -- no pixel comes back to the host."""
         image = np.ascontiguousarray(image, dtype=np.uint8)
         if image.ndim != 3 or image.shape[2] != 3:
             raise ValueError("split_array expects an HxWx3 uint8 RGB image")
@@ -249,8 +276,15 @@ class TilingModule:
         d_img = ctx.upload(image)
         d_tiles = ctx.alloc(n * block * block * 3)
         ctx.tile_extract_pad(d_img.ptr, ih, iw, 3, iw * 3, positions, block, self.padding_mode.value, d_tiles.ptr)
-        data = ctx.download(d_tiles.ptr, (n, block, block, 3), np.uint8)
-        d_img.free(); d_tiles.free()
+        data, scores = None, None
+        if device_resident:
+            self.release_device_tiles()
+            self.device_tiles = DeviceTileSet(ctx, d_img, d_tiles, n, block, ih, iw)
+            if self.enable_content_aware:
+                scores = ctx.gray_std_u8(d_tiles.ptr, n, block * block * 3, block * 3, block, block)
+        else:
+            data = ctx.download(d_tiles.ptr, (n, block, block, 3), np.uint8)
+            d_img.free(); d_tiles.free()
         tiles: List[Tile] = []
         for idx, (x, y, w, h) in enumerate(positions):
             top, bottom, left, right = self._calculate_overlap_for_tile(x, y, w, h, iw, ih)
@@ -258,8 +292,10 @@ class TilingModule:
                                 output_w=int(w * self.output_scale), output_h=int(h * self.output_scale),
                                 overlap_top=top, overlap_bottom=bottom, overlap_left=left, overlap_right=right,
                                 image_hash=image_hash, status=TileStatus.PENDING)
-            tile_img = data[idx]
-            if self.enable_content_aware:
+            tile_img = data[idx] if data is not None else None
+            if scores is not None:
+                meta.complexity_score = float(scores[idx])
+            elif self.enable_content_aware:
                 # the reference applies COLOR_BGR2GRAY to RGB data (tiling_module.py:748): R/B swapped
                 t = tile_img.astype(np.int64)
                 gray = (t[..., 0] * 3735 + t[..., 1] * 19235 + t[..., 2] * 9798 + (1 << 14)) >> 15
@@ -274,6 +310,12 @@ class TilingModule:
             'image_path': image_path, 'image_width': iw, 'image_height': ih, 'num_tiles': len(tiles),
             'tile_ids': [t.metadata.block_id for t in tiles], 'timestamp': time.time()}
         return tiles
+
+    def release_device_tiles(self):
+        ts = getattr(self, "device_tiles", None)
+        if ts is not None:
+            ts.free()
+        self.device_tiles = None
 
     def _build_neighbor_relationships(self, tiles: List[Tile]):
         xywh = [(t.metadata.global_x, t.metadata.global_y, t.metadata.input_w, t.metadata.input_h) for t in tiles]

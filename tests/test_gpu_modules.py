@@ -166,6 +166,24 @@ def test_pipeline_end_to_end(rng, tmp_path):
     assert np.array_equal(fused, ref)
     assert res.quality_report['full_reference']['psnr'] == pytest.approx(oc.psnr(img, ref[:150, :200]), rel=1e-12)
     assert os.path.exists(str(tmp_path / "out" / "result_qa_report.json"))
+    # the default path is device-resident: the decoded source is the only upload, the canvas the only download
+    # (metric sums and the per-tile gray moments are a few hundred bytes)
+    tr = pipe.transfers
+    assert tr["h2d_bytes"] == img.nbytes == tr["source_bytes"]
+    assert tr["canvas_bytes"] == fused.nbytes <= tr["d2h_bytes"] <= fused.nbytes + 4096
+    assert pipe.tiling_module.device_tiles is None                      # released after the run
+    # ... and gives what the host-array path (tiles and canvas through NumPy at every stage) gives
+    cfg_h = sr_main.PipelineConfig(block_size=96, overlap_ratio=0.2, sr_scale=2, num_pyramid_levels=4, device_resident=False)
+    pipe_h = sr_main.SuperResolutionPipeline(cfg_h)
+    res_h = asyncio.run(pipe_h.process(src, str(tmp_path / "host.png"), prompt="x"))
+    assert res_h.success and np.array_equal(np.asarray(Image.open(str(tmp_path / "host.png"))), fused)
+    fr_d, fr_h = res.quality_report['full_reference'], res_h.quality_report['full_reference']
+    assert fr_d.keys() == fr_h.keys() and all(fr_d[k] == fr_h[k] for k in fr_d)
+    t_dev = pipe.tiling_module.split_array(img, device_resident=True)
+    t_host = pipe_h.tiling_module.split_array(img)
+    pipe.tiling_module.release_device_tiles()
+    assert all(a.data is None and b.data is not None for a, b in zip(t_dev, t_host))
+    assert [a.metadata.complexity_score for a in t_dev] == pytest.approx([b.metadata.complexity_score for b in t_host], rel=1e-12)
     # a failing tile is dropped from the blend, the run still succeeds (main.py:310-325)
     calls = {"n": 0}
 

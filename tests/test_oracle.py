@@ -165,3 +165,38 @@ def test_merge_tiles_oracle_partition():
     tiles = [np.full((40, 60, 3), 200, np.uint8)] * 2
     out = onp.merge_tiles(tiles, metas, 100, 40, 1.0, True)
     assert out.shape == (40, 100, 3) and set(np.unique(out)) <= {199, 200}
+
+
+def test_feather_weights_are_one_and_distance_transform_restatement():
+    """feather_blend (blending_module.py:1313-1337) takes cv2.distanceTransform of an all-ones mask: no zero pixel, every
+    distance saturates, weight == 1.  The chamfer restatement itself: exact on axis-aligned distances, 1.4 / 2.1969
+    metrics on the knight / diagonal moves (16.16 fixed point)."""
+    from oracle import oracle_np as onp
+    d = onp.distance_transform_l2_5(np.ones((7, 9), np.uint8))
+    assert d.min() == d.max() == np.float32(8192.0)
+    assert np.all(onp.feather_weight_map(7, 9) == 1.0) and np.all(onp.feather_weight_map(200, 300) == 1.0)
+    m = np.ones((9, 9), np.uint8)
+    m[4, 4] = 0
+    d = onp.distance_transform_l2_5(m)
+    assert d[4, 4] == 0 and d[4, 8] == 4.0 and d[0, 4] == 4.0
+    assert abs(d[3, 3] - 1.4) < 1e-4 and abs(d[2, 3] - 2.1969) < 1e-4 and abs(d[0, 0] - 4 * 1.4) < 1e-3
+
+
+def test_color_correction_oracle_properties():
+    from oracle import oracle_np as onp
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, (40, 48, 3), dtype=np.uint8)
+    # matching an image to itself: the table is the identity on every value that occurs
+    for c in range(3):
+        h = np.bincount(img[..., c].ravel(), minlength=256)
+        lut = onp.histogram_lut(h, h)
+        assert np.array_equal(lut[img[..., c]], img[..., c])
+    assert np.array_equal(onp.color_correction(img, img, "histogram", local_filter=False), img)
+    # box mean of a constant is the constant; the 8x8 window is anchored at 4 (x-4 .. x+3)
+    assert np.all(onp.box_blur_f32(np.full((9, 11), 3.25, np.float32), 8) == np.float32(3.25))
+    imp = np.zeros((20, 20), np.float32)
+    imp[10, 10] = 64.0
+    b = onp.box_blur_f32(imp, 8)
+    assert b[10 - 3, 10 - 3] == 1.0 and b[10 + 4, 10 + 4] == 1.0 and b[10 + 5, 10] == 0.0 and b[10 - 4, 10] == 0.0
+    t = onp.mean_std_table(np.bincount(img[..., 0].ravel(), minlength=256), np.bincount(img[..., 0].ravel(), minlength=256))
+    assert np.allclose(t, np.arange(256), atol=1e-3)
