@@ -315,6 +315,17 @@ SR_API int sr_color_correct_u8(sr_ctx *ctx, const uint8_t *d_img, int64_t stride
                                const float *h_glut, int local_filter, int radius, float eps, uint8_t *d_out,
                                int64_t out_stride);
 
+/* ---- output writers: stage 5 of SuperResolutionPipeline.process (main.py:399-404) -----------------------
+ * Host-only (no context, no GPU), multi-threaded (threads <= 0: every hardware thread).  h_img: h x w x cn u8, row stride in
+ * bytes.  TIFF: LZW-compressed strips (Pillow compression='tiff_lzw'; BigTIFF above 4 GB); PNG: deflate level `level`
+ * (Pillow compress_level=3), filter None; JPEG: baseline YCbCr 4:2:0 (gray for cn 1) with libjpeg's quality scaling,
+ * colour conversion, down-sampling, islow DCT and standard Huffman tables (Pillow quality=95 defaults), restart marker per
+ * MCU row.  The lossless files decode to the input bytes; the JPEG decodes to what Pillow's own file decodes to. */
+SR_API int sr_encode_tiff_lzw(const uint8_t *h_img, int h, int w, int cn, int64_t stride, const char *path, int threads);
+SR_API int sr_encode_png(const uint8_t *h_img, int h, int w, int cn, int64_t stride, int level, const char *path, int threads);
+SR_API int sr_encode_jpeg(const uint8_t *h_img, int h, int w, int cn, int64_t stride, int quality, const char *path,
+                          int threads);
+
 /* ---- LPIPS (quality_assessment_module.py:419-465 calculate_lpips, :197-224 _to_lpips_tensor, :135-146 model init) -------
  * The reference delegates to the package `lpips` (requirements.txt:16): net 'alex' or 'vgg', version 0.1.  Weights are
  * supplied by the caller (nothing is fetched): h_conv_w[i] = i-th convolution of the backbone, dense OIHW fp32,

@@ -124,6 +124,9 @@ SIGNATURES = {
     "sr_gray_moments_u8": (_i, [_vp, _vp, _i, _i64, _i64, _i, _i, _i, _i, C.POINTER(C.c_uint64)]),
     "sr_histogram_u8": (_i, [_vp, _vp, _i64, _i, _i, _i, C.POINTER(C.c_uint64)]),
     "sr_color_correct_u8": (_i, [_vp, _vp, _i64, _i, _i, _i, C.POINTER(C.c_float), _i, _i, C.c_float, _vp, _i64]),
+    "sr_encode_tiff_lzw": (_i, [_vp, _i, _i, _i, _i64, C.c_char_p, _i]),
+    "sr_encode_png": (_i, [_vp, _i, _i, _i, _i64, _i, C.c_char_p, _i]),
+    "sr_encode_jpeg": (_i, [_vp, _i, _i, _i, _i64, _i, C.c_char_p, _i]),
     "sr_lpips_create": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), _i, C.POINTER(_vp), _i, _vp, _vp, C.POINTER(_vp)]),
     "sr_lpips_destroy": (_i, [_vp]),
     "sr_lpips_layer_sizes": (_i, [_i, _i, _i, _pi]),
@@ -253,6 +256,28 @@ def strip_tile_rows(rects_xywh, levels: int, canvas_h: int, row_begin: int, row_
     out = (C.c_int * (2 * n))()
     check(load().sr_strip_tile_rows(rects, n, int(levels), int(canvas_h), int(row_begin), int(row_end), out))
     return [(out[2 * i], out[2 * i + 1]) for i in range(n)]
+
+
+def write_image(arr: np.ndarray, path: str, threads: int = 0, png_level: int = 3, jpeg_quality: int = 95) -> str:
+    """Stage 5 of the pipeline (main.py:399-404) with the native multi-threaded writers: .tif / .tiff -> TIFF-LZW,
+    .png -> PNG (compress_level 3), anything else -> JPEG quality 95.  arr: HxW or HxWxC uint8.  Returns the format."""
+    a = np.ascontiguousarray(arr)
+    if a.dtype != np.uint8 or a.ndim not in (2, 3):
+        raise ValueError("write_image expects an HxW or HxWxC uint8 array")
+    h, w = a.shape[:2]
+    cn = a.shape[2] if a.ndim == 3 else 1
+    lib, p, low = load(), os.fsencode(path), str(path).lower()
+    ptr = a.ctypes.data_as(C.c_void_p)
+    if low.endswith(".tif") or low.endswith(".tiff"):
+        check(lib.sr_encode_tiff_lzw(ptr, h, w, cn, w * cn, p, threads))
+        return "TIFF"
+    if low.endswith(".png"):
+        check(lib.sr_encode_png(ptr, h, w, cn, w * cn, png_level, p, threads))
+        return "PNG"
+    if cn == 4:
+        raise ValueError("cannot write an RGBA image as JPEG")       # Pillow raises OSError here
+    check(lib.sr_encode_jpeg(ptr, h, w, cn, w * cn, jpeg_quality, p, threads))
+    return "JPEG"
 
 
 def pyramid_halo(levels: int) -> Tuple[int, int]:

@@ -129,17 +129,12 @@ class SuperResolutionPipeline:
         return list(await asyncio.gather(*[limited(t) for t in tiles]))
 
     def _write_outputs(self, fused: np.ndarray, output_path: str, report: Optional[Dict[str, Any]]):
-        """Stage 5 (main.py:399-410): TIFF-LZW / PNG (compress_level 3) / JPEG-95 by extension + the QA report JSON."""
-        from PIL import Image
+        """Stage 5 (main.py:399-410): TIFF-LZW / PNG (compress_level 3) / JPEG-95 by extension + the QA report JSON.
+        The reference calls Pillow's single-threaded writers; here the three formats are written by the native
+        multi-threaded encoders behind the C ABI (sr_encode_*): same pixels back from any decoder."""
+        import _native
         Path(output_path).parent.mkdir(parents=True, exist_ok=True)
-        img = Image.fromarray(fused)
-        low = output_path.lower()
-        if low.endswith('.tiff') or low.endswith('.tif'):
-            img.save(output_path, format='TIFF', compression='tiff_lzw')
-        elif low.endswith('.png'):
-            img.save(output_path, format='PNG', compress_level=3)
-        else:
-            img.save(output_path, quality=95)
+        _native.write_image(fused, output_path, png_level=3, jpeg_quality=95)
         if report:
             with open(output_path.rsplit('.', 1)[0] + '_qa_report.json', 'w', encoding='utf-8') as f:
                 json.dump(report, f, indent=2, ensure_ascii=False, default=str)

@@ -7,8 +7,9 @@ with border padding and the feather merge run as HIP kernels.  No CPU compute fa
 
 Not on this path: ContentAnalyzer (Haar / MSER / saliency need OpenCV models) -- tiles
 are never moved by it in the reference either (positions are always the uniform grid), so only the
-``roi_flags`` annotation is absent.  The L1/L2 cache and the JSON checkpoint are host-side
-persistence and are kept in a small form (npz instead of pickle for L2).
+``roi_flags`` annotation is absent.  The L1/L2 tile caches and the JSON checkpoint are host-side
+persistence outside the tile -> blend -> assess path and are NOT rebuilt; only the constructor's cache-directory
+side effect and the ``restore_from_cache`` probe of main.py:299-304 exist.
 
 Reference quirks kept: the last-row/column overlap override (can exceed the tile size), merge_tiles
 resizing padded tiles into the unpadded output size and casting without clip, the cache directory
@@ -24,7 +25,6 @@ import os
 import threading
 import time
 import uuid
-from collections import OrderedDict
 from dataclasses import asdict, dataclass, field
 from enum import Enum, auto
 from pathlib import Path
@@ -115,42 +115,6 @@ class Tile:
         return (x1, y1, x2, y2)
 
 
-class LRUCache:
-    """L1 in-memory tile cache (tiling_module.py:373-425)."""
-
-    def __init__(self, max_size: int = 100):
-        self.max_size = max_size
-        self.cache: "OrderedDict[str, Tile]" = OrderedDict()
-        self.lock = threading.Lock()
-
-    def get(self, key: str) -> Optional[Tile]:
-        with self.lock:
-            if key in self.cache:
-                self.cache.move_to_end(key)
-                return self.cache[key]
-            return None
-
-    def put(self, key: str, value: Tile):
-        with self.lock:
-            if key in self.cache:
-                self.cache.move_to_end(key)
-            self.cache[key] = value
-            while len(self.cache) > self.max_size:
-                self.cache.popitem(last=False)
-
-    def remove(self, key: str) -> bool:
-        with self.lock:
-            return self.cache.pop(key, None) is not None
-
-    def clear(self):
-        with self.lock:
-            self.cache.clear()
-
-    def keys(self) -> List[str]:
-        with self.lock:
-            return list(self.cache.keys())
-
-
 class DeviceTileSet:
     """What split_array(device_resident=True) leaves in HBM: the source image and its n padded block x block tiles."""
 
@@ -198,7 +162,7 @@ class TilingModule:
         self.output_size = int(block_size * output_scale)
         self.overlap_pixels = int(block_size * overlap_ratio)
         self.content_analyzer = None          # out of scope, see module docstring
-        self.l1_cache = LRUCache(max_size=l1_cache_size)
+        self.l1_cache_size = l1_cache_size    # accepted for signature parity; the tile caches are out of scope
         if l2_cache_dir is None:
             l2_cache_dir = os.path.expanduser("~/.cache/super_resolution/tiling")
         self.l2_cache_dir = Path(l2_cache_dir)
@@ -341,89 +305,21 @@ class TilingModule:
         img = _load_rgb(image_path)
         return img[m.global_y:m.global_y + m.input_h, m.global_x:m.global_x + m.input_w]
 
-    # -- cache / checkpoint (host-side persistence) -------------------------------------
-    def save_tile_cache(self, tile: Tile, cache_level: CacheLevel, custom_path: Optional[str] = None) -> str:
-        path = custom_path
-        if cache_level == CacheLevel.L1_MEMORY:
-            self.l1_cache.put(tile.metadata.block_id, tile)
-            tile.metadata.status = TileStatus.CACHED
-            path = f"L1://{tile.metadata.block_id}"
-        elif cache_level == CacheLevel.L2_DISK:
-            if path is None:
-                path = str(self.l2_cache_dir / f"{tile.metadata.block_id}.npz")
-            np.savez(path, metadata=json.dumps(tile.metadata.to_dict()),
-                     data=tile.data if tile.data is not None else np.zeros(0, np.uint8),
-                     has_data=tile.data is not None)
-            tile.cache_path = path
-            tile.metadata.status = TileStatus.CACHED
-        else:
-            path = f"L3://{tile.metadata.block_id}"
-        tile.metadata.updated_at = time.time()
-        return path
-
-    def load_tile_cache(self, tile_id: str, cache_level: Optional[CacheLevel] = None) -> Optional[Tile]:
-        if cache_level is None or cache_level == CacheLevel.L1_MEMORY:
-            tile = self.l1_cache.get(tile_id)
-            if tile is not None:
-                return tile
-        if cache_level is None or cache_level == CacheLevel.L2_DISK:
-            path = self.l2_cache_dir / f"{tile_id}.npz"
-            if path.exists():
-                try:
-                    with np.load(path, allow_pickle=False) as z:
-                        meta = TileMetadata.from_dict(json.loads(str(z["metadata"])))
-                        data = z["data"] if bool(z["has_data"]) else None
-                    tile = Tile(metadata=meta, data=data, cache_path=str(path))
-                    self.l1_cache.put(tile_id, tile)
-                    return tile
-                except Exception as exc:  # noqa: BLE001
-                    logger.error("加载L2缓存失败: %s", exc)
-        return None
-
-    def save_checkpoint(self, image_hash: str, checkpoint_path: Optional[str] = None) -> str:
-        if checkpoint_path is None:
-            checkpoint_path = str(self.l2_cache_dir / f"checkpoint_{image_hash}.json")
-        if image_hash not in self.processing_state:
-            raise ValueError(f"未找到图像哈希 {image_hash} 的处理状态")
-        state = dict(self.processing_state[image_hash])
-        state['tile_states'] = {tid: {'status': self.tile_registry[tid].metadata.status.name,
-                                      'metadata': self.tile_registry[tid].metadata.to_dict()}
-                                for tid in state['tile_ids'] if tid in self.tile_registry}
-        with open(checkpoint_path, 'w') as f:
-            json.dump(state, f, indent=2)
-        return checkpoint_path
-
+    # -- cache / checkpoint: OUT OF SCOPE (host-side persistence, not compute) --------------------
+    # The reference's L1 LRU / L2 pickle cache and JSON checkpoint (tiling_module.py:373-425,899-1072) are not rebuilt.
+    # What the pipeline touches is one probe (main.py:299-304: hash the file, ask for a checkpoint, ignore the answer):
     def restore_from_cache(self, image_hash: str) -> Optional[Dict]:
+        """The probe main.py:299-304 makes: the checkpoint record for this image if a reference run left one in the
+        cache directory, else None.  Nothing is restored from it."""
         path = self.l2_cache_dir / f"checkpoint_{image_hash}.json"
         if not path.exists():
             return None
         try:
             with open(path, 'r') as f:
-                state = json.load(f)
-            for tid, ts in state.get('tile_states', {}).items():
-                tile = self.load_tile_cache(tid, CacheLevel.L2_DISK)
-                if tile is not None:
-                    tile.metadata.status = TileStatus[ts['status']]
-                    with self.registry_lock:
-                        self.tile_registry[tid] = tile
-            self.processing_state[image_hash] = state
-            return state
-        except Exception as exc:  # noqa: BLE001
+                return json.load(f)
+        except (OSError, ValueError) as exc:
             logger.error("恢复检查点失败: %s", exc)
             return None
-
-    def clear_cache(self, cache_level: Optional[CacheLevel] = None):
-        if cache_level is None or cache_level == CacheLevel.L1_MEMORY:
-            self.l1_cache.clear()
-        if cache_level is None or cache_level == CacheLevel.L2_DISK:
-            for f in self.l2_cache_dir.glob("*.npz"):
-                f.unlink()
-
-    def get_cache_stats(self) -> Dict:
-        l2 = list(self.l2_cache_dir.glob("*.npz"))
-        return {'l1_memory': {'count': len(self.l1_cache.keys()), 'keys': self.l1_cache.keys()},
-                'l2_disk': {'count': len(l2), 'size_mb': sum(f.stat().st_size for f in l2) / (1024 * 1024)},
-                'tile_registry': {'count': len(self.tile_registry)}}
 
     # -- feather merge (tiling_module.py:1074-1175) ----------------------------------------------------
     def merge_tiles(self, tiles: List[Tile], output_width: int, output_height: int, blending: bool = True) -> np.ndarray:
