@@ -1676,7 +1676,7 @@ __device__ __forceinline__ unsigned long long assess_load_chunk(const unsigned c
                 ga = va[0];
                 gb = vb[0];
             }
-            XY[ly][lx] = (unsigned)ga | ((unsigned)gb << 16);
+            XY[ly][lx] = (unsigned)ga | ((unsigned)gb << 14);
             QQ[ly][lx] = (unsigned)__mul24(ga, gb);
             PP[ly][lx] = (unsigned)(__mul24(ga, ga) + __mul24(gb, gb));
             if (want_sse && lr >= AM_R && lr < AM_R + P.ty && gy < P.ry1 && gy < P.h && lx >= AM_R && lx < AM_R + AM_TX &&
@@ -1732,7 +1732,7 @@ __device__ __forceinline__ unsigned long long assess_load_chunk(const unsigned c
         unsigned txy[4], tq[4], tp[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            txy[k] = (unsigned)ga[k] | ((unsigned)gb[k] << 16);
+            txy[k] = (unsigned)ga[k] | ((unsigned)gb[k] << 14);
             tq[k] = (unsigned)__mul24(ga[k], gb[k]);
             tp[k] = (unsigned)(__mul24(ga[k], ga[k]) + __mul24(gb[k], gb[k]));
         }
@@ -1751,33 +1751,69 @@ __device__ __forceinline__ unsigned long long assess_load_chunk(const unsigned c
     return sse;
 }
 
-// GAUSS = false drops the Gaussian variants at compile time (no 88-register FIFO): SSE and / or uniform-7 only.
-template <int CN, bool RESIZE, bool GAUSS>
-__global__ __launch_bounds__(256) void k_assess_march(const unsigned char *__restrict__ a, long long sa,
+// An address the compiler cannot fold into its users: the eleven taps of a row are then read with ds_read2_b32 off ONE
+// base register per array and row (the 8-bit dword offsets of ds_read2 do not reach across rows, and left alone the
+// compiler materialises five bases per array and row with VALU adds).
+typedef __attribute__((address_space(3))) const unsigned lds_cu32;
+__device__ __forceinline__ lds_cu32 *lds_row_base(const unsigned *p)
+{
+    lds_cu32 *q = (lds_cu32 *)p;          // stays an LDS pointer (ds_read, not flat_load) through the opaque step
+    asm volatile("" : "+v"(q));
+    return q;
+}
+
+// 1 / d for the SSIM quotient: hardware estimate + one Newton step (relative error ~1e-15; the metric's bar is 1e-9
+// against the oracle, 1e-4 against the reference)
+__device__ __forceinline__ double ssim_recip(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    return fma(fma(-d, r, 1.0), r, r);
+}
+
+__device__ __forceinline__ double ssim_quot(double ux, double uy, double spq, double dpq, double c1, double c2)
+{
+    // spq = uxx + uyy,  dpq = uxy
+    const double uxuy = ux * uy, uu = ux * ux + uy * uy;
+    const double a1 = 2.0 * uxuy + c1, a2 = 2.0 * (dpq - uxuy) + c2;
+    const double b1 = uu + c1, b2 = (spq - uu) + c2;
+    return (a1 * a2) * ssim_recip(b1 * b2);
+}
+
+// Compile-time variants: GAUSS (the two Gaussian-11 sums and their 88-register FIFO), UNIF (the uniform-7 sum and its LDS
+// ring), SAMEC (data_range == 255: the cropped and the full-frame Gaussian variants share one SSIM value per pixel).
+// What the march does per row, in instruction terms: 33 LDS dwords, 15 integer pair sums, 24 conversions + 24 fp64
+// multiply-adds (row pass), 20 fp64 adds + 24 multiply-adds (column pass), ~20 fp64 operations per SSIM value; validity of
+// a ROW is block-uniform (scalar branches), validity of a COLUMN is applied once, to the thread's sums, after the march
+// (out-of-image columns hold reflected data, so their values are finite and simply dropped).
+// In LDS x and y travel packed as x | y << 14: pair sums (<= 510), 7-tap sums (<= 1785) and 49-sample window sums
+// (<= 12495 < 2^14) all stay inside their fields, so one integer add serves both images at every stage.
+template <int CN, bool RESIZE, bool GAUSS, bool UNIF, bool SAMEC>
+__global__ __launch_bounds__(256, 3) void k_assess_march(const unsigned char *__restrict__ a, long long sa,
                                                       const unsigned char *__restrict__ b, long long sb,
                                                       AssessParams P, double *__restrict__ part)
 {
-    __shared__ __attribute__((aligned(16))) unsigned XY[AM_CH][AM_GP];   // x | y << 16
+    __shared__ __attribute__((aligned(16))) unsigned XY[AM_CH][AM_GP];   // x | y << 14
     __shared__ __attribute__((aligned(16))) unsigned QQ[AM_CH][AM_GP];   // x * y
     __shared__ __attribute__((aligned(16))) unsigned PP[AM_CH][AM_GP];   // x^2 + y^2
-    __shared__ int U[7][2][AM_TX];      // per-row 7-tap sums, 61 bits packed: {sx:11, sy:11, sq lo:10}, {sp:21, sq hi:9}
+    // per-row 7-tap sums of the last seven rows, two dwords per column: {sx:14 | sy:11 @14 | sq lo:7 @25}, {sp:20 | sq hi:12 @20}
+    __shared__ unsigned U[UNIF ? 7 : 1][2][AM_TX];
     __shared__ double red[4][4];
     const int c = threadIdx.x;
     const int bx0 = blockIdx.x * AM_TX, by0 = P.ry0 + blockIdx.y * P.ty;
     const int rows_needed = min(P.ty, P.ry1 - by0) + 2 * AM_R;          // block-uniform
     const int mx = bx0 + c;
-    const bool col_ok = mx < P.w;
-    const bool do_u = (P.flags & ASSESS_UNIFORM) != 0, do_g = GAUSS && (P.flags & (ASSESS_GAUSS | ASSESS_SIMPLE)) != 0;
-    const bool u_col = mx >= 3 && mx < P.w - 3, g_col = mx >= AM_R && mx < P.w - AM_R;
-    double f[4][11];
+    double f[GAUSS ? 4 : 1][11];
+    if (GAUSS) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int i = 0; i < 11; ++i) f[m][i] = 0.0;
-    int t_xy = 0, t_p = 0, t_q = 0;
+            for (int i = 0; i < 11; ++i) f[m][i] = 0.0;
+    }
+    unsigned t_xy = 0, t_p = 0, t_q = 0;                                // 49-sample window sums (uniform-7)
     double sum_int = 0.0, sum_all = 0.0, sum_u = 0.0;
     unsigned long long sse = 0;
     int slot = 0;                                                       // row index mod 7
+    const double k0 = P.k[0], k1 = P.k[1], k2 = P.k[2], k3 = P.k[3], k4 = P.k[4], k5 = P.k[5];
 #pragma unroll 1
     for (int ch = 0; ch < P.nch; ++ch) {
         if (ch * AM_CH >= rows_needed) break;
@@ -1787,92 +1823,97 @@ __global__ __launch_bounds__(256) void k_assess_march(const unsigned char *__res
 #pragma unroll
         for (int s = 0; s < AM_CH; ++s) {
             const int r = ch * AM_CH + s;
-            if (r < rows_needed) {
-                unsigned xy[11], qv[11], pv[11];
+            if (r >= rows_needed) continue;                             // block-uniform (no break: the loop must unroll)
+            lds_cu32 *rxy = lds_row_base(&XY[s][c]), *rq = lds_row_base(&QQ[s][c]), *rp = lds_row_base(&PP[s][c]);
+            unsigned xy[11], qv[11], pv[11];
 #pragma unroll
-                for (int j = 0; j < 11; ++j) {
-                    xy[j] = XY[s][c + j];
-                    qv[j] = QQ[s][c + j];
-                    pv[j] = PP[s][c + j];
-                }
-                // symmetric pair sums, shared by the Gaussian row pass (all five) and the 7-tap box sums (the first three)
-                unsigned sxy[6], sp[6], sq[6];
-                sxy[0] = xy[5]; sp[0] = pv[5]; sq[0] = qv[5];
+            for (int j = 0; j < 11; ++j) {
+                xy[j] = rxy[j];
+                qv[j] = rq[j];
+                pv[j] = rp[j];
+            }
+            // symmetric pair sums, shared by the Gaussian row pass (all five) and the 7-tap box sums (the first three)
+            unsigned sxy[6], sp[6], sq[6];
+            sxy[0] = xy[5]; sp[0] = pv[5]; sq[0] = qv[5];
+#pragma unroll
+            for (int j = 1; j <= (GAUSS ? AM_R : 3); ++j) {
+                sxy[j] = xy[5 - j] + xy[5 + j];                         // both images in one add
+                sp[j] = pv[5 - j] + pv[5 + j];
+                sq[j] = qv[5 - j] + qv[5 + j];
+            }
+            if (GAUSS) {
+                const double kk[6] = {k0, k1, k2, k3, k4, k5};
+                double hx = (double)(sxy[0] & 0x3FFFu) * kk[0], hy = (double)(sxy[0] >> 14) * kk[0];
+                double hp = (double)sp[0] * kk[0], hq = (double)sq[0] * kk[0];
 #pragma unroll
                 for (int j = 1; j <= AM_R; ++j) {
-                    if (j > 3 && !do_g) continue;
-                    sxy[j] = xy[5 - j] + xy[5 + j];                 // both pair sums in one add (each < 2^16)
-                    sp[j] = pv[5 - j] + pv[5 + j];
-                    sq[j] = qv[5 - j] + qv[5 + j];
+                    hx = fma((double)(sxy[j] & 0x3FFFu), kk[j], hx);
+                    hy = fma((double)(sxy[j] >> 14), kk[j], hy);
+                    hp = fma((double)sp[j], kk[j], hp);
+                    hq = fma((double)sq[j], kk[j], hq);
                 }
-                if (do_g) {
-                    double hx = (double)(sxy[0] & 0xFFFFu) * P.k[0], hy = (double)(sxy[0] >> 16) * P.k[0];
-                    double hp = (double)sp[0] * P.k[0], hq = (double)sq[0] * P.k[0];
-#pragma unroll
-                    for (int j = 1; j <= AM_R; ++j) {
-                        hx = fma((double)(sxy[j] & 0xFFFFu), P.k[j], hx);
-                        hy = fma((double)(sxy[j] >> 16), P.k[j], hy);
-                        hp = fma((double)sp[j], P.k[j], hp);
-                        hq = fma((double)sq[j], P.k[j], hq);
-                    }
-                    f[0][s] = hx; f[1][s] = hy; f[2][s] = hp; f[3][s] = hq;
+                f[0][s] = hx; f[1][s] = hy; f[2][s] = hp; f[3][s] = hq;
+            }
+            if (UNIF) {
+                const unsigned uxy = ((sxy[0] + sxy[1]) + sxy[2]) + sxy[3];
+                const unsigned up = ((sp[0] + sp[1]) + sp[2]) + sp[3];
+                const unsigned uq = ((sq[0] + sq[1]) + sq[2]) + sq[3];
+                if (r >= 7) {                                           // block-uniform: the slot holds row r - 7
+                    const unsigned o0 = U[slot][0][c], o1 = U[slot][1][c];
+                    t_xy -= o0 & 0x1FFFFFFu;
+                    t_p -= o1 & 0xFFFFFu;
+                    t_q -= (o0 >> 25) | ((o1 >> 20) << 7);
                 }
-                if (do_u) {
-                    const unsigned uxy = ((sxy[0] + sxy[1]) + sxy[2]) + sxy[3];
-                    const unsigned up = ((sp[0] + sp[1]) + sp[2]) + sp[3];
-                    const unsigned uq = ((sq[0] + sq[1]) + sq[2]) + sq[3];
-                    if (r >= 7) {
-                        const unsigned o0 = (unsigned)U[slot][0][c], o1 = (unsigned)U[slot][1][c];
-                        t_xy -= (int)((o0 & 0x7FFu) | (((o0 >> 11) & 0x7FFu) << 16));
-                        t_p -= (int)(o1 & 0x1FFFFFu);
-                        t_q -= (int)((o0 >> 22) | ((o1 >> 21) << 10));
-                    }
-                    t_xy += (int)uxy; t_p += (int)up; t_q += (int)uq;
-                    U[slot][0][c] = (int)((uxy & 0x7FFu) | ((uxy >> 16) << 11) | ((uq & 0x3FFu) << 22));
-                    U[slot][1][c] = (int)(up | ((uq >> 10) << 21));
-                    const int orow = r - 8, my = by0 + orow;             // window rows r-6 .. r, centre r-3
-                    if (orow >= 0 && orow < P.ty && my < P.ry1 && my >= 3 && my < P.h - 3 && u_col) {
-                        // SSIM of the 49-sample window with both fractions scaled to integers: with S. the window sums,
-                        //   (2 ux uy + C1) / (ux^2 + uy^2 + C1) = (2 Sx Sy + 49^2 C1) / (Sx^2 + Sy^2 + 49^2 C1)
-                        //   (2 cov + C2) / (var_x + var_y + C2) = (2 (49 Sxy - Sx Sy) + 48*49 C2)
-                        //                                         / (49 (Sxx + Syy) - (Sx^2 + Sy^2) + 48*49 C2)
-                        // (sample covariance, N - 1 = 48).  Everything left of the constants is exact 32-bit integer
-                        // arithmetic (|values| < 3.2e8); fp64 enters with the constants.
-                        const int sx = t_xy & 0xFFFF, sy = (int)((unsigned)t_xy >> 16);
-                        const int sxsy = __mul24(sx, sy), ss = __mul24(sx, sx) + __mul24(sy, sy);
-                        const int ncov = 49 * t_q - sxsy, nvar = 49 * t_p - ss;
-                        const double a1 = fma(2.0, (double)sxsy, P.k1u), a2 = fma(2.0, (double)ncov, P.k2u);
-                        const double b1 = (double)ss + P.k1u, b2 = (double)nvar + P.k2u;
-                        sum_u += (a1 * a2) * fast_recip(b1 * b2);
-                    }
-                }
-                if (do_g && r >= 2 * AM_R) {
-                    const int orow = r - 2 * AM_R, my = by0 + orow;      // rows r-10 .. r are in the FIFO, centre r-5
-                    if (orow < P.ty && my < P.ry1 && my < P.h && col_ok) {
-                        double u[4];
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) {
-                            double acc = f[m][(s + 6) % 11] * P.k[0];
-#pragma unroll
-                            for (int j = 1; j <= AM_R; ++j)
-                                acc = fma(f[m][(s + 6 + 11 - j) % 11] + f[m][(s + 6 + j) % 11], P.k[j], acc);
-                            u[m] = acc;
-                        }
-                        const bool interior = my >= AM_R && my < P.h - AM_R && g_col;
-                        if (P.same_c) {
-                            const double sv = ssim_value(u[0], u[1], u[2], u[3], P.c1a, P.c2a);
-                            sum_all += sv;
-                            if (interior) sum_int += sv;
-                        } else {
-                            if (P.flags & ASSESS_SIMPLE) sum_all += ssim_value(u[0], u[1], u[2], u[3], P.c1b, P.c2b);
-                            if (interior && (P.flags & ASSESS_GAUSS)) sum_int += ssim_value(u[0], u[1], u[2], u[3], P.c1a, P.c2a);
-                        }
-                    }
-                }
+                t_xy += uxy; t_p += up; t_q += uq;
+                U[slot][0][c] = uxy | (uq << 25);
+                U[slot][1][c] = up | ((uq >> 7) << 20);
                 slot = slot == 6 ? 0 : slot + 1;
+                const int orow = r - 8, my = by0 + orow;                // window rows r-6 .. r, centre r-3
+                if (orow >= 0 && orow < P.ty && my < P.ry1 && my >= 3 && my < P.h - 3) {        // block-uniform
+                    // SSIM of the 49-sample window with both fractions scaled to integers: with S. the window sums,
+                    //   (2 ux uy + C1) / (ux^2 + uy^2 + C1) = (2 Sx Sy + 49^2 C1) / (Sx^2 + Sy^2 + 49^2 C1)
+                    //   (2 cov + C2) / (var_x + var_y + C2) = (2 (49 Sxy - Sx Sy) + 48*49 C2)
+                    //                                         / (49 (Sxx + Syy) - (Sx^2 + Sy^2) + 48*49 C2)
+                    // (sample covariance, N - 1 = 48).  Everything left of the constants is exact 32-bit integer
+                    // arithmetic (|values| < 3.2e8, every factor below 2^24); fp64 enters with the constants.
+                    const int sx = (int)(t_xy & 0x3FFFu), sy = (int)(t_xy >> 14);
+                    const int sxsy = __mul24(sx, sy), ss = __mul24(sx, sx) + __mul24(sy, sy);
+                    const int ncov = __mul24(49, (int)t_q) - sxsy, nvar = __mul24(49, (int)t_p) - ss;
+                    const double a1 = fma(2.0, (double)sxsy, P.k1u), a2 = fma(2.0, (double)ncov, P.k2u);
+                    const double b1 = (double)ss + P.k1u, b2 = (double)nvar + P.k2u;
+                    sum_u += (a1 * a2) * ssim_recip(b1 * b2);
+                }
+            }
+            if (GAUSS && r >= 2 * AM_R) {
+                const int orow = r - 2 * AM_R, my = by0 + orow;         // rows r-10 .. r are in the FIFO, centre r-5
+                if (orow < P.ty && my < P.ry1 && my < P.h) {            // block-uniform
+                    const double kk[6] = {k0, k1, k2, k3, k4, k5};
+                    double u[4];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        double acc = f[m][(s + 6) % 11] * kk[0];
+#pragma unroll
+                        for (int j = 1; j <= AM_R; ++j)
+                            acc = fma(f[m][(s + 6 + 11 - j) % 11] + f[m][(s + 6 + j) % 11], kk[j], acc);
+                        u[m] = acc;
+                    }
+                    const bool inner_row = my >= AM_R && my < P.h - AM_R;       // block-uniform
+                    if (SAMEC) {
+                        const double sv = ssim_quot(u[0], u[1], u[2], u[3], P.c1a, P.c2a);
+                        sum_all += sv;
+                        if (inner_row) sum_int += sv;
+                    } else {
+                        if (P.flags & ASSESS_SIMPLE) sum_all += ssim_quot(u[0], u[1], u[2], u[3], P.c1b, P.c2b);
+                        if (inner_row && (P.flags & ASSESS_GAUSS)) sum_int += ssim_quot(u[0], u[1], u[2], u[3], P.c1a, P.c2a);
+                    }
+                }
             }
         }
     }
+    // column validity, once: the full-frame variant counts every image column, the cropped ones lose 5 / 3 per side
+    if (!(mx < P.w)) sum_all = 0.0;
+    if (!(mx >= AM_R && mx < P.w - AM_R)) sum_int = 0.0;
+    if (!(mx >= 3 && mx < P.w - 3)) sum_u = 0.0;
     sum_int = wave_sum_f64(sum_int);
     sum_all = wave_sum_f64(sum_all);
     sum_u = wave_sum_f64(sum_u);
@@ -3525,15 +3566,20 @@ static int assess_impl(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const 
         {
             ProfScope ps(ctx, scope);
             const dim3 grid((unsigned)gbx, (unsigned)gby), block(256);
-#define LAUNCH_ASSESS(CNV, RS, GS)                                                                                   \
-    hipLaunchKernelGGL((k_assess_march<CNV, RS, GS>), grid, block, 0, ctx->stream, d_a, (long long)stride_a, d_b,       \
+#define LAUNCH_ASSESS(CNV, RS, GS, US, SC)                                                                           \
+    hipLaunchKernelGGL((k_assess_march<CNV, RS, GS, US, SC>), grid, block, 0, ctx->stream, d_a, (long long)stride_a, d_b, \
                        (long long)stride_b, P, part)
-#define LAUNCH_ASSESS_G(CNV, RS)                                                                                     \
-    do { if (gauss) LAUNCH_ASSESS(CNV, RS, true); else LAUNCH_ASSESS(CNV, RS, false); } while (0)
-            const bool gauss = (flags & (ASSESS_GAUSS | ASSESS_SIMPLE)) != 0;
-            if (cn == 3) { if (resized) LAUNCH_ASSESS_G(3, true); else LAUNCH_ASSESS_G(3, false); }
-            else         { if (resized) LAUNCH_ASSESS_G(1, true); else LAUNCH_ASSESS_G(1, false); }
-#undef LAUNCH_ASSESS_G
+#define LAUNCH_ASSESS_V(CNV, RS)                                                                                        \
+    do {                                                                                                                \
+        if (gauss && unif) { if (P.same_c) LAUNCH_ASSESS(CNV, RS, true, true, true); else LAUNCH_ASSESS(CNV, RS, true, true, false); } \
+        else if (gauss) { if (P.same_c) LAUNCH_ASSESS(CNV, RS, true, false, true); else LAUNCH_ASSESS(CNV, RS, true, false, false); } \
+        else if (unif) LAUNCH_ASSESS(CNV, RS, false, true, true);                                                       \
+        else LAUNCH_ASSESS(CNV, RS, false, false, true);                                                                \
+    } while (0)
+            const bool gauss = (flags & (ASSESS_GAUSS | ASSESS_SIMPLE)) != 0, unif = (flags & ASSESS_UNIFORM) != 0;
+            if (cn == 3) { if (resized) LAUNCH_ASSESS_V(3, true); else LAUNCH_ASSESS_V(3, false); }
+            else         { if (resized) LAUNCH_ASSESS_V(1, true); else LAUNCH_ASSESS_V(1, false); }
+#undef LAUNCH_ASSESS_V
 #undef LAUNCH_ASSESS
             hipLaunchKernelGGL(k_assess_finish, dim3(1), dim3(256), 0, ctx->stream, part, (long long)nblk, flags, d_out);
         }

@@ -147,27 +147,41 @@ class SuperResolutionPipeline:
         from tiling_module import _load_rgb
         tm, s = self.tiling_module, self.config.sr_scale
         self.transfers = None
+        st = self.stage_times = {}
+        t_mark = time.perf_counter()
+
+        def lap(name):
+            nonlocal t_mark
+            ctx.sync()
+            now = time.perf_counter()
+            st[name] = now - t_mark
+            t_mark = now
+
         original = _load_rgb(input_path)
         ih, iw = original.shape[:2]
         ctx = self.quality_module._ctx()
         h2d0, d2h0 = ctx.h2d_bytes, ctx.d2h_bytes
+        lap("decode")
         # Stage 1: tiling (metadata on the host, pixels stay on the GPU)
         tiles = tm.split_array(original, image_hash=tm._compute_image_hash(input_path), image_path=input_path,
                                device_resident=True)
         ts = tm.device_tiles
         block, out_block = tm.block_size, tm.block_size * s
         sr_bufs, canvas = [], None
+        lap("upload+tile")
         try:
             # Stage 2: SR stand-in, tile by tile, HBM -> HBM
             for i in range(len(tiles)):
                 buf = ctx.alloc(out_block * out_block * 3)
                 sr_bufs.append(buf)
                 ctx.resize_cubic_u8(ts.tile_ptr(i), block * 3, block, block, 3, buf.ptr, out_block * 3, out_block, out_block)
+            lap("sr_stub")
             # Stage 3: blending (the canvas is cropped to the un-padded image, scaled)
             rects = [(t.metadata.global_x * s, t.metadata.global_y * s, out_block, out_block) for t in tiles]
             H, W = ih * s, iw * s
             canvas = self.blending_module.fuse_device([b.ptr for b in sr_bufs], [out_block * 3] * len(tiles), rects, (H, W), 3,
                                                       laplacian=self.config.blend_method != 'weighted')
+            lap("blend")
             # Stage 4: quality assessment, source (still resident from stage 1) vs canvas
             report, score = None, None
             if self.config.enable_qa:
@@ -177,8 +191,10 @@ class SuperResolutionPipeline:
                           'commercial': self.quality_module.evaluate_commercial(None, roi_regions or []),
                           'timestamp': datetime.now().isoformat()}
                 score = qa.get('overall_score', 0)
+            lap("assess")
             # Stage 5: the one download, then the writer
             fused = ctx.download(canvas.ptr, (H, W, 3), np.uint8)
+            lap("download")
         finally:
             ctx.sync()
             for b in sr_bufs + ([canvas] if canvas is not None else []):
@@ -187,6 +203,7 @@ class SuperResolutionPipeline:
         self.transfers = {"h2d_bytes": ctx.h2d_bytes - h2d0, "d2h_bytes": ctx.d2h_bytes - d2h0,
                           "source_bytes": int(original.nbytes), "canvas_bytes": int(fused.nbytes)}
         self._write_outputs(fused, output_path, report)
+        st["write"] = time.perf_counter() - t_mark
         return PipelineResult(True, output_path, time.time() - start, len(tiles), len(tiles), 0, score, report, None)
 
     async def process(self, input_path: str, output_path: str, prompt: str = "",

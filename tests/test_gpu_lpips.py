@@ -131,3 +131,33 @@ def test_quality_module_lpips_surface(rng, tmp_path):
     assert abs(full["overall_score"] - want) < 1e-9
     for k in ("psnr", "ssim", "ms_ssim"):
         assert full[k] == base[k]
+
+
+def test_config5_lpips_at_200mp(ctx, models):
+    """BASELINE config 5 ("200MP content-aware tiling + full PSNR/SSIM/LPIPS on-GPU"), LPIPS leg at the full canvas size:
+    no oracle finishes in seconds there, so size-independent properties -- the tile-streamed forward fits HBM (relu1_1
+    alone would be 51 GB per image untiled), LPIPS(x, x) == 0, the sums over disjoint tile ranges (what 8 ranks would
+    each compute) add up to the whole, and a different tile size gives the same value."""
+    import torch
+    import device_pipeline as dp
+    geo = dp.workload_geometry("200MP-kd")
+    H, W = geo.canvas_h, geo.canvas_w
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    a = torch.randint(0, 256, (H, W * 3), dtype=torch.uint8, device=dev, generator=gen)
+    b = (a.to(torch.int16) + torch.randint(-9, 10, (H, W * 3), dtype=torch.int16, device=dev, generator=gen)).clamp_(0, 255).to(torch.uint8)
+    torch.cuda.synchronize()
+    model = models["alex"][0]
+    n = model.tile_count(H, W, 4096)
+    assert n == 5 * 3
+    whole = model.layer_sums(a.data_ptr(), W * 3, b.data_ptr(), W * 3, H, W, 3, 4096)
+    ranks = [model.layer_sums(a.data_ptr(), W * 3, b.data_ptr(), W * 3, H, W, 3, 4096, r * n // 8, (r + 1) * n // 8) for r in range(8)]
+    for k in range(5):
+        assert whole[k] > 0 and abs(sum(r[k] for r in ranks) - whole[k]) <= 1e-12 * whole[k]
+    other = model.layer_sums(a.data_ptr(), W * 3, b.data_ptr(), W * 3, H, W, 3, 2048)
+    for k in range(5):
+        assert abs(other[k] - whole[k]) <= 1e-9 * whole[k]
+    assert model.value(a.data_ptr(), W * 3, a.data_ptr(), W * 3, H, W, 3, tile=4096) == 0.0
+    vgg = models["vgg"][0]
+    v, layers = vgg.value(a.data_ptr(), W * 3, b.data_ptr(), W * 3, H, W, 3, tile=2048, per_layer=True)
+    assert np.isfinite(v) and v > 0 and all(x > 0 for x in layers)
