@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -1755,10 +1756,11 @@ __device__ __forceinline__ unsigned long long assess_load_chunk(const unsigned c
 // base register per array and row (the 8-bit dword offsets of ds_read2 do not reach across rows, and left alone the
 // compiler materialises five bases per array and row with VALU adds).
 typedef __attribute__((address_space(3))) const unsigned lds_cu32;
-__device__ __forceinline__ lds_cu32 *lds_row_base(const unsigned *p)
+__device__ __forceinline__ lds_cu32 *lds_row_base(lds_cu32 *row0, int bytes)
 {
-    lds_cu32 *q = (lds_cu32 *)p;          // stays an LDS pointer (ds_read, not flat_load) through the opaque step
-    asm volatile("" : "+v"(q));
+    // one explicit VALU add per array and row off the thread's row-0 address: no per-row base registers kept alive
+    lds_cu32 *q;
+    asm volatile("v_add_u32 %0, %2, %1" : "=v"(q) : "v"(row0), "n"(bytes));     // literal goes in src0
     return q;
 }
 
@@ -1773,8 +1775,8 @@ __device__ __forceinline__ double ssim_recip(double d)
 __device__ __forceinline__ double ssim_quot(double ux, double uy, double spq, double dpq, double c1, double c2)
 {
     // spq = uxx + uyy,  dpq = uxy
-    const double uxuy = ux * uy, uu = ux * ux + uy * uy;
-    const double a1 = 2.0 * uxuy + c1, a2 = 2.0 * (dpq - uxuy) + c2;
+    const double uxuy = ux * uy, uu = fma(ux, ux, uy * uy);
+    const double a1 = fma(2.0, uxuy, c1), a2 = fma(2.0, dpq - uxuy, c2);
     const double b1 = uu + c1, b2 = (spq - uu) + c2;
     return (a1 * a2) * ssim_recip(b1 * b2);
 }
@@ -1814,6 +1816,8 @@ __global__ __launch_bounds__(256, 3) void k_assess_march(const unsigned char *__
     unsigned long long sse = 0;
     int slot = 0;                                                       // row index mod 7
     const double k0 = P.k[0], k1 = P.k[1], k2 = P.k[2], k3 = P.k[3], k4 = P.k[4], k5 = P.k[5];
+    lds_cu32 *xy0 = (lds_cu32 *)&XY[0][c], *q0 = (lds_cu32 *)&QQ[0][c], *p0 = (lds_cu32 *)&PP[0][c];
+    double sum_edge = 0.0;                                              // full-frame samples of the 5 top / bottom image rows
 #pragma unroll 1
     for (int ch = 0; ch < P.nch; ++ch) {
         if (ch * AM_CH >= rows_needed) break;
@@ -1824,7 +1828,7 @@ __global__ __launch_bounds__(256, 3) void k_assess_march(const unsigned char *__
         for (int s = 0; s < AM_CH; ++s) {
             const int r = ch * AM_CH + s;
             if (r >= rows_needed) continue;                             // block-uniform (no break: the loop must unroll)
-            lds_cu32 *rxy = lds_row_base(&XY[s][c]), *rq = lds_row_base(&QQ[s][c]), *rp = lds_row_base(&PP[s][c]);
+            lds_cu32 *rxy = lds_row_base(xy0, s * AM_GP * 4), *rq = lds_row_base(q0, s * AM_GP * 4), *rp = lds_row_base(p0, s * AM_GP * 4);
             unsigned xy[11], qv[11], pv[11];
 #pragma unroll
             for (int j = 0; j < 11; ++j) {
@@ -1899,9 +1903,11 @@ __global__ __launch_bounds__(256, 3) void k_assess_march(const unsigned char *__
                     }
                     const bool inner_row = my >= AM_R && my < P.h - AM_R;       // block-uniform
                     if (SAMEC) {
+                        // one SSIM value serves both variants: the cropped sum is the full-frame sum minus the (at most
+                        // ten) image rows outside the crop, which only the blocks at the top / bottom ever see
                         const double sv = ssim_quot(u[0], u[1], u[2], u[3], P.c1a, P.c2a);
                         sum_all += sv;
-                        if (inner_row) sum_int += sv;
+                        if (!inner_row) sum_edge += sv;
                     } else {
                         if (P.flags & ASSESS_SIMPLE) sum_all += ssim_quot(u[0], u[1], u[2], u[3], P.c1b, P.c2b);
                         if (inner_row && (P.flags & ASSESS_GAUSS)) sum_int += ssim_quot(u[0], u[1], u[2], u[3], P.c1a, P.c2a);
@@ -1911,6 +1917,7 @@ __global__ __launch_bounds__(256, 3) void k_assess_march(const unsigned char *__
         }
     }
     // column validity, once: the full-frame variant counts every image column, the cropped ones lose 5 / 3 per side
+    if (GAUSS && SAMEC) sum_int = sum_all - sum_edge;
     if (!(mx < P.w)) sum_all = 0.0;
     if (!(mx >= AM_R && mx < P.w - AM_R)) sum_int = 0.0;
     if (!(mx >= 3 && mx < P.w - 3)) sum_u = 0.0;
@@ -3550,6 +3557,10 @@ static int assess_impl(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const 
         // block marches) -- long blocks amortise the 10-row halo, short ones avoid a mostly empty last round on strips.
         const long long gbx = (w + AM_TX - 1) / AM_TX;
         const long long slots = (long long)std::max(ctx->num_cu, 1) * 3;
+        // Measured (profiles/r02_assess_nch.json): longer blocks do NOT pay although they amortise the 10-row halo and
+        // can fill the chip in exact rounds -- 25 / 33 / 49 chunks run 1.60 / 1.64 / 1.70 ms against 1.55 ms for 12: blocks
+        // that start together stay in lockstep, so every wave of a CU sits in its load phase (or its fp64 march) at
+        // the same time; many short blocks drift apart and overlap the two.
         long long best_cost = -1;
         for (int n = 2; n <= AM_NCH_MAX; ++n) {
             const int ty = AM_CH * n - 2 * AM_R;

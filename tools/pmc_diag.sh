@@ -7,9 +7,9 @@ OUT=gpurun_out/pmc_$TAG
 export TMPDIR=/tmp
 rm -rf "$OUT"; mkdir -p "$OUT"
 i=0
-for GROUP in "VALUBusy MemUnitStalled" "OccupancyPercent VALUUtilization" "VmemLatency SQ_WAIT_INST_ANY SQ_WAVE_CYCLES" "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_BUSY_CYCLES"; do
+for GROUP in "VALUBusy MemUnitStalled" "OccupancyPercent VALUUtilization" "SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT" "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU"; do
   i=$((i+1))
-  rocprofv3 --pmc $GROUP --kernel-trace --output-format csv -d "$OUT/g$i" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof --no-pcie \
+  rocprofv3 --pmc $GROUP --kernel-trace --output-format csv -d "$OUT/g$i" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof --no-pcie --sweep none \
       > /dev/null 2> "$OUT/g$i.err" || echo "group $i failed"
 done
 python3 - "$OUT" <<'PY'
