@@ -78,7 +78,7 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=min(4, max(len(jobs), 1))) as ex:
         list(ex.map(run, jobs))
-    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden", "-o", LIB] + objs + ["-lpthread"])
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden", "-o", LIB] + objs + ["-lpthread", "-lz"])
     with open(DIGEST_FILE, "w") as f:
         f.write(digest + "\n")
     return LIB

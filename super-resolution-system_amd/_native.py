@@ -12,7 +12,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsrhip.so")
+LIB_PATH = os.environ.get("SR_LIB_PATH") or os.path.join(_HERE, "libsrhip.so")   # SR_LIB_PATH: an experiment build
 
 SR_OK = 0
 SR_ERR_INVALID_ARG, SR_ERR_SHAPE, SR_ERR_OOM, SR_ERR_HIP, SR_ERR_COMM, SR_ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6
@@ -171,7 +171,7 @@ def load():
         spec = importlib.util.spec_from_file_location("_sr_build", os.path.join(_HERE, "_build.py"))
         bld = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(bld)
-        if bld._stale():                 # missing, or older than a source / header: never run a stale binary silently
+        if not os.environ.get("SR_LIB_PATH") and bld._stale():                 # missing, or older than a source / header: never run a stale binary silently
             try:
                 bld.build_native()
             except Exception as exc:  # noqa: BLE001

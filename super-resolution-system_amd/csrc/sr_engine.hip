@@ -826,14 +826,17 @@ __device__ __forceinline__ void gather_tile_fast(const FinalDesc &D, const float
     }
     float w0[2][4];
     tile_weights_interior(D, luts, lx0, ly0, w0);
-    if (DT == SRC_U8 && CN == 3) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const unsigned wds[3] = {qs[j].x, qs[j].y, qs[j].z};
-#pragma unroll
-            for (int b = 0; b < 12; ++b) g0[j][b / 3][b % 3] = (float)((wds[b >> 2] >> (8 * (b & 3))) & 0xFFu);
+    // u8 RGB: the pixels stay packed (6 dwords) and each plane's eight values are pulled out when that plane is
+    // processed (v_cvt_f32_ubyteN, one instruction per value either way): 18 fewer live registers than unpacking up front
+    constexpr bool LAZY = (DT == SRC_U8 && CN == 3);
+    auto px = [&](int j, int k, int c) -> float {
+        if (LAZY) {
+            const int b = 3 * k + c;
+            const unsigned wd = (b >> 2) == 0 ? qs[j].x : ((b >> 2) == 1 ? qs[j].y : qs[j].z);
+            return (float)((wd >> (8 * (b & 3))) & 0xFFu);
         }
-    }
+        return g0[j][k][c];
+    };
     if (pyr) {                               // tile-uniform: a real branch, not a select per value
         // plane by plane: the six 16-byte loads of a plane are in flight together, the next plane's are issued
         // before this plane's arithmetic (two planes of level-1 data live at a time, not three)
@@ -852,6 +855,7 @@ __device__ __forceinline__ void gather_tile_fast(const FinalDesc &D, const float
         }
 #pragma unroll
         for (int c = 0; c < CN; ++c) {
+#ifndef SR_FINAL_NOPREF
             if (c + 1 < CN) {
                 const char *gb = (const char *)(arena + D.g1 + (c + 1) * splane);
                 const char *rb = (const char *)(arena + D.r1 + (c + 1) * splane);
@@ -861,6 +865,17 @@ __device__ __forceinline__ void gather_tile_fast(const FinalDesc &D, const float
                     nr[r] = ld_f4_a4((const float *)(rb + (o + r * rowb)));
                 }
             }
+#else
+            if (c > 0) {
+                const char *gb = (const char *)(arena + D.g1 + c * splane);
+                const char *rb = (const char *)(arena + D.r1 + c * splane);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    qg[r] = ld_f4_a4((const float *)(gb + (o + r * rowb)));
+                    qr[r] = ld_f4_a4((const float *)(rb + (o + r * rowb)));
+                }
+            }
+#endif
             float ug[2][4], ur[2][4];
             up_regs<XO, YO>(qg, ug);
             up_regs<XO, YO>(qr, ur);
@@ -868,14 +883,16 @@ __device__ __forceinline__ void gather_tile_fast(const FinalDesc &D, const float
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float lap = g0[j][k][c] - ug[j][k];
+                    const float lap = px(j, k, c) - ug[j][k];
                     const float wl = lap * w0[j][k];
                     acc[j][k][c] += ur[j][k] + wl;
                 }
+#ifndef SR_FINAL_NOPREF
             if (c + 1 < CN) {
 #pragma unroll
                 for (int r = 0; r < 3; ++r) { qg[r] = ng[r]; qr[r] = nr[r]; }
             }
+#endif
         }
     } else {
 #pragma unroll
@@ -883,7 +900,7 @@ __device__ __forceinline__ void gather_tile_fast(const FinalDesc &D, const float
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) acc[j][k][c] += g0[j][k][c] * w0[j][k];
+                for (int k = 0; k < 4; ++k) acc[j][k][c] += px(j, k, c) * w0[j][k];
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -1138,8 +1155,11 @@ __device__ __forceinline__ void final_edge_block(const FinalDesc *__restrict__ d
 // Final gather.  Blocks with blockIdx.y < edge_rows work through the edge list (above); the others are the regular
 // 256 x 8 pixel blocks: threads all of whose tile visits are interior compute here, threads with any border visit
 // leave their pixels to the edge blocks.
+#ifndef SR_FINAL_WAVES
+#define SR_FINAL_WAVES 3
+#endif
 template <int DT, bool LAP, int CN>
-__global__ __launch_bounds__(256, 3) void k_final_fast(const FinalDesc *__restrict__ descs,
+__global__ __launch_bounds__(256, SR_FINAL_WAVES) void k_final_fast(const FinalDesc *__restrict__ descs,
                                                        const int *__restrict__ cand_off, const int *__restrict__ cand_idx,
                                                        const int4 *__restrict__ edge_blocks, const int *__restrict__ edge_cand,
                                                        int n_edge, int edge_rows,
@@ -1598,9 +1618,11 @@ __device__ __forceinline__ double ssim_value(double ux, double uy, double spq, d
 // from chunk to chunk: the only recomputed halo is the 10 rows at the top of a block (8 %).  The uniform-7 variant
 // rides along: its per-row 7-tap integer sums go through a 7-slot per-column ring in LDS.
 // ---------------------------------------------------------------------------------------------
-#define AM_TX 256
+#ifndef AM_TX
+#define AM_TX 256                        /* columns (= threads) per block */
+#endif
 #define AM_R 5
-#define AM_GP 272                       /* row pitch in pixels: 68 groups of 4 */
+#define AM_GP (AM_TX + 16)              /* row pitch in pixels: 10 halo columns, rounded up to groups of 4 */
 #define AM_CH 11                        /* rows per chunk == FIFO depth */
 #define AM_NCH_MAX 12                   /* chunks per block: P.nch <= 12, chosen per launch (rows / tail effect) */
 /* a block marches 11 * nch rows and produces P.ty = 11 * nch - 10 of them; LDS 36 KB + 14 KB ring -> 3 blocks per CU */
@@ -1660,7 +1682,7 @@ __device__ __forceinline__ unsigned long long assess_load_chunk(const unsigned c
         // one resized pixel per step, both images, kept as a rolled loop: the sampling (4 rows x 4 taps x CN, 64-bit
         // accumulators) is register-hungry and the march that follows needs its 150 VGPRs for three waves per SIMD
 #pragma unroll 1
-        for (int i = threadIdx.x; i < AM_CH * AM_GP; i += 256) {
+        for (int i = threadIdx.x; i < AM_CH * AM_GP; i += AM_TX) {
             const int ly = i / AM_GP, lx = i - ly * AM_GP;
             const int lr = ch * AM_CH + ly;
             if (lr >= rows_needed) break;
@@ -1688,7 +1710,7 @@ __device__ __forceinline__ unsigned long long assess_load_chunk(const unsigned c
         }
         return sse;
     }
-    for (int i = threadIdx.x; i < AM_CH * (AM_GP / 4); i += 256) {
+    for (int i = threadIdx.x; i < AM_CH * (AM_GP / 4); i += AM_TX) {
         const int ly = i / (AM_GP / 4), lx = (i - ly * (AM_GP / 4)) * 4;
         const int lr = ch * AM_CH + ly;
         if (lr >= rows_needed) break;                       // rows grow with i
@@ -1790,7 +1812,7 @@ __device__ __forceinline__ double ssim_quot(double ux, double uy, double spq, do
 // In LDS x and y travel packed as x | y << 14: pair sums (<= 510), 7-tap sums (<= 1785) and 49-sample window sums
 // (<= 12495 < 2^14) all stay inside their fields, so one integer add serves both images at every stage.
 template <int CN, bool RESIZE, bool GAUSS, bool UNIF, bool SAMEC>
-__global__ __launch_bounds__(256, 3) void k_assess_march(const unsigned char *__restrict__ a, long long sa,
+__global__ __launch_bounds__(AM_TX, 3) void k_assess_march(const unsigned char *__restrict__ a, long long sa,
                                                       const unsigned char *__restrict__ b, long long sb,
                                                       AssessParams P, double *__restrict__ part)
 {
@@ -1799,7 +1821,7 @@ __global__ __launch_bounds__(256, 3) void k_assess_march(const unsigned char *__
     __shared__ __attribute__((aligned(16))) unsigned PP[AM_CH][AM_GP];   // x^2 + y^2
     // per-row 7-tap sums of the last seven rows, two dwords per column: {sx:14 | sy:11 @14 | sq lo:7 @25}, {sp:20 | sq hi:12 @20}
     __shared__ unsigned U[UNIF ? 7 : 1][2][AM_TX];
-    __shared__ double red[4][4];
+    __shared__ double red[AM_TX / 64][4];
     const int c = threadIdx.x;
     const int bx0 = blockIdx.x * AM_TX, by0 = P.ry0 + blockIdx.y * P.ty;
     const int rows_needed = min(P.ty, P.ry1 - by0) + 2 * AM_R;          // block-uniform
@@ -1934,7 +1956,10 @@ __global__ __launch_bounds__(256, 3) void k_assess_march(const unsigned char *__
     __syncthreads();
     if (c < 4) {
         const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-        part[blk * 4 + c] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+        double t = red[0][c];
+#pragma unroll
+        for (int wv = 1; wv < AM_TX / 64; ++wv) t += red[wv][c];
+        part[blk * 4 + c] = t;
     }
 }
 
@@ -3576,7 +3601,7 @@ static int assess_impl(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const 
         double *part = (double *)scr;
         {
             ProfScope ps(ctx, scope);
-            const dim3 grid((unsigned)gbx, (unsigned)gby), block(256);
+            const dim3 grid((unsigned)gbx, (unsigned)gby), block(AM_TX);
 #define LAUNCH_ASSESS(CNV, RS, GS, US, SC)                                                                           \
     hipLaunchKernelGGL((k_assess_march<CNV, RS, GS, US, SC>), grid, block, 0, ctx->stream, d_a, (long long)stride_a, d_b, \
                        (long long)stride_b, P, part)
