@@ -5,7 +5,8 @@
 // pipeline, so the three formats are written here with every core:
 //   * TIFF / LZW   : strips of 16 rows, each strip an independent LZW stream (TIFF 6.0, MSB-first codes, early change),
 //                    strips compressed in parallel.
-//   * PNG          : filter 0 rows, raw deflate of independent ~1 MiB row chunks in parallel, each ended by a full flush
+//   * PNG          : adaptively filtered rows (libpng's minimum-sum-of-absolute-differences choice among the five
+//                    filters), raw deflate of independent ~1 MiB row chunks in parallel, each ended by a full flush
 //                    (byte-aligned, no back-reference leaves a chunk), concatenated into one zlib stream; the chunks'
 //                    Adler-32 values are combined.
 //   * JPEG         : baseline, YCbCr 4:2:0, libjpeg's quality scaling of the Annex K tables, its fixed-point colour
@@ -21,6 +22,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -429,11 +431,36 @@ int sr_encode_png(const uint8_t *h_img, int h, int w, int cn, int64_t stride, in
     std::atomic<int> failed{0};
     parallel_for(nchunks, threads, [&](size_t c) {
         const int y0 = (int)c * rows_per_chunk, y1 = std::min(h, y0 + rows_per_chunk);
-        std::vector<uint8_t> raw((size_t)(y1 - y0) * frow);
+        std::vector<uint8_t> raw((size_t)(y1 - y0) * frow), cand(4 * rowlen);
+        const std::vector<uint8_t> zero(rowlen, 0);
         for (int y = y0; y < y1; ++y) {
+            // Adaptive filtering with libpng's default heuristic: try None / Sub / Up / Average / Paeth and keep the
+            // filter whose output has the smallest sum of |signed byte| (the previous ROW is raw image data, so chunks
+            // stay independent).  Level 0 (stored) skips the search.
             uint8_t *d = raw.data() + (size_t)(y - y0) * frow;
-            d[0] = 0;                                                     // filter type None
-            memcpy(d + 1, h_img + (size_t)y * stride, rowlen);
+            const uint8_t *cur = h_img + (size_t)y * stride;
+            const uint8_t *up = y > 0 ? h_img + (size_t)(y - 1) * stride : zero.data();
+            int best = 0;
+            if (level > 0) {
+                uint64_t sum[5] = {0, 0, 0, 0, 0};
+                uint8_t *f1 = cand.data(), *f2 = f1 + rowlen, *f3 = f2 + rowlen, *f4 = f3 + rowlen;
+                for (size_t i = 0; i < rowlen; ++i) {
+                    const int x = cur[i], a = i >= (size_t)cn ? cur[i - cn] : 0, b = up[i], c = i >= (size_t)cn ? up[i - cn] : 0;
+                    const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+                    const int pr = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+                    const uint8_t v1 = (uint8_t)(x - a), v2 = (uint8_t)(x - b), v3 = (uint8_t)(x - ((a + b) >> 1)), v4 = (uint8_t)(x - pr);
+                    f1[i] = v1; f2[i] = v2; f3[i] = v3; f4[i] = v4;
+                    sum[0] += x < 128 ? x : 256 - x;
+                    sum[1] += v1 < 128 ? v1 : 256 - v1;
+                    sum[2] += v2 < 128 ? v2 : 256 - v2;
+                    sum[3] += v3 < 128 ? v3 : 256 - v3;
+                    sum[4] += v4 < 128 ? v4 : 256 - v4;
+                }
+                for (int k = 1; k < 5; ++k)
+                    if (sum[k] < sum[best]) best = k;
+            }
+            d[0] = (uint8_t)best;
+            memcpy(d + 1, best == 0 ? cur : cand.data() + (size_t)(best - 1) * rowlen, rowlen);
         }
         raw_len[c] = raw.size();
         adler[c] = adler32(adler32(0L, Z_NULL, 0), raw.data(), (uInt)raw.size());
