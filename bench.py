@@ -70,7 +70,7 @@ def algorithmic_bytes(geo) -> dict:
 ROCPROF_NAMES = {"tile_extract": "k_tile_extract", "down_l0": "k_down_march<0, 3>",
                  "down_l1p": "k_down_march<2, 3>",
                  "up_level": "k_up_level_blk<3>", "final_gather": "k_final_fast<0, true, 3>",
-                 "assess_all": "k_assess_march<3, false, true>"}
+                 "assess_all": "k_assess_march<3, false, true, true, true>"}
 
 
 def measured_traffic() -> dict:
@@ -88,6 +88,7 @@ def measured_traffic() -> dict:
         if vals:
             out[fam] = sum(vals)
     out["_source"] = os.path.basename(files[-1])
+    out["_note"] = data.get("note")
     return out
 
 

@@ -1162,33 +1162,40 @@ __device__ __forceinline__ void final_edge_block(const FinalDesc *__restrict__ d
     store_pixels<CN>(acc, wacc, canvas, cstride, canvas_f32, cw, x0, y0, nx, ny);
 }
 
-// Final gather.  Blocks with blockIdx.y < edge_rows work through the edge list (above); the others are the regular
-// 256 x 8 pixel blocks: threads all of whose tile visits are interior compute here, threads with any border visit
-// leave their pixels to the edge blocks.
+// Final gather.  The first n_edge blocks of the (one-dimensional) grid work through the edge list (above); the others
+// are the regular FIN_BW x FIN_BH pixel blocks: threads all of whose tile visits are interior compute here, threads with
+// any border visit leave their pixels to the edge blocks.
 #ifndef SR_FINAL_WAVES
 #define SR_FINAL_WAVES 3
 #endif
+#ifndef FIN_TX
+#define FIN_TX 64                 /* threads across a regular block */
+#endif
+#define FIN_TY (256 / FIN_TX)
+#define FIN_BW (4 * FIN_TX)       /* canvas pixels per regular block */
+#define FIN_BH (2 * FIN_TY)
 template <int DT, bool LAP, int CN>
 __global__ __launch_bounds__(256, SR_FINAL_WAVES) void k_final_fast(const FinalDesc *__restrict__ descs,
                                                        const int *__restrict__ cand_off, const int *__restrict__ cand_idx,
                                                        const int4 *__restrict__ edge_blocks, const int *__restrict__ edge_cand,
-                                                       int n_edge, int edge_rows,
+                                                       int n_edge, int nbx_r,
                                                        const float *__restrict__ arena, const float *__restrict__ luts,
                                                        unsigned char *__restrict__ canvas, long long cstride,
                                                        float *__restrict__ canvas_f32, int cw, int row_begin, int row_end)
 {
-    if ((int)blockIdx.y < edge_rows) {
-        const int ebi = blockIdx.y * gridDim.x + blockIdx.x;
-        if (ebi < n_edge)
-            final_edge_block<DT, LAP, CN>(descs, edge_blocks, ebi, edge_cand, arena, luts, canvas, cstride, canvas_f32, cw,
-                                          row_begin, row_end);
+    if ((int)blockIdx.x < n_edge) {
+        final_edge_block<DT, LAP, CN>(descs, edge_blocks, (int)blockIdx.x, edge_cand, arena, luts, canvas, cstride, canvas_f32, cw,
+                                      row_begin, row_end);
         return;
     }
-    const int by = blockIdx.y - edge_rows;
-    const int blk = by * gridDim.x + blockIdx.x;
+    // regular blocks: FIN_BW x FIN_BH canvas pixels, FIN_TX x FIN_TY threads of 4 x 2 pixels (a wave covers
+    // 64 / FIN_TX thread rows).  Squarer blocks re-read fewer level-1 halo rows: a block needs FIN_BH / 2 + 2 of them.
+    const int blk = (int)blockIdx.x - n_edge;
+    const int by = blk / nbx_r, bx = blk - by * nbx_r;
     const int c_begin = cand_off[blk], c_end = cand_off[blk + 1];
-    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int y0 = row_begin + (by * 4 + threadIdx.y) * 2;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const int x0 = (bx * FIN_TX + (tid % FIN_TX)) * 4;
+    const int y0 = row_begin + (by * FIN_TY + tid / FIN_TX) * 2;
     if (x0 >= cw || y0 >= row_end) return;
     const int nx = min(4, cw - x0), ny = min(2, row_end - y0);
     float acc[2][4][CN], wacc[2][4];
@@ -2873,22 +2880,23 @@ int sr_blend_plan_create(sr_ctx *ctx, const sr_tile_rect *h_tiles, int n, int cn
             if ((e = hipMalloc((void **)&P->d_edge_cand, sizeof(int) * std::max<size_t>(ecand.size(), 1))) != hipSuccess) return fail(e, "edge candidates");
             if (!ecand.empty() && (e = hipMemcpy(P->d_edge_cand, ecand.data(), sizeof(int) * ecand.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload");
         }
-        // candidate tiles per block, CSR, tiles in list order (the accumulation order of the reference)
-        const size_t nblk = (size_t)std::max(nbx, 1) * std::max(nby, 1);
+        // candidate tiles per regular block, CSR, tiles in list order (the accumulation order of the reference)
+        const int nbx_r = std::max((canvas_w + FIN_BW - 1) / FIN_BW, 1), nby_r = std::max((rows + FIN_BH - 1) / FIN_BH, 1);
+        const size_t nblk = (size_t)nbx_r * nby_r;
         std::vector<int> coff(nblk + 1, 0);
         auto block_span = [&](const TileDev &T, int &bx_a, int &bx_b, int &by_a, int &by_b) {
             const long long x0 = std::max<long long>(T.x, 0), x1 = std::min<long long>((long long)T.x + T.w, canvas_w);
             const long long y0 = std::max<long long>(T.y, row_begin), y1 = std::min<long long>((long long)T.y + T.h, row_end);
             if (x0 >= x1 || y0 >= y1) return false;
-            bx_a = (int)(x0 / 256); bx_b = (int)((x1 - 1) / 256);
-            by_a = (int)((y0 - row_begin) / 8); by_b = (int)((y1 - 1 - row_begin) / 8);
+            bx_a = (int)(x0 / FIN_BW); bx_b = (int)((x1 - 1) / FIN_BW);
+            by_a = (int)((y0 - row_begin) / FIN_BH); by_b = (int)((y1 - 1 - row_begin) / FIN_BH);
             return true;
         };
         for (int t = 0; t < n && rows > 0; ++t) {
             int bxa, bxb, bya, byb;
             if (!block_span(P->tiles[t], bxa, bxb, bya, byb)) continue;
             for (int by = bya; by <= byb; ++by)
-                for (int bx = bxa; bx <= bxb; ++bx) ++coff[(size_t)by * nbx + bx + 1];
+                for (int bx = bxa; bx <= bxb; ++bx) ++coff[(size_t)by * nbx_r + bx + 1];
         }
         for (size_t i = 0; i < nblk; ++i) coff[i + 1] += coff[i];
         std::vector<int> cidx((size_t)std::max(coff[nblk], 1), 0), fill(coff.begin(), coff.end() - 1);
@@ -2896,7 +2904,7 @@ int sr_blend_plan_create(sr_ctx *ctx, const sr_tile_rect *h_tiles, int n, int cn
             int bxa, bxb, bya, byb;
             if (!block_span(P->tiles[t], bxa, bxb, bya, byb)) continue;
             for (int by = bya; by <= byb; ++by)
-                for (int bx = bxa; bx <= bxb; ++bx) cidx[(size_t)fill[(size_t)by * nbx + bx]++] = t;
+                for (int bx = bxa; bx <= bxb; ++bx) cidx[(size_t)fill[(size_t)by * nbx_r + bx]++] = t;
         }
         if ((e = hipMalloc((void **)&P->d_cand_off, sizeof(int) * coff.size())) != hipSuccess) return fail(e, "candidate table");
         if ((e = hipMalloc((void **)&P->d_cand_idx, sizeof(int) * cidx.size())) != hipSuccess) return fail(e, "candidate table");
@@ -3092,11 +3100,11 @@ static int blend_gather(sr_blend_plan *P, bool lap, int dtype, void *const *h_d_
     {
         ProfScope ps(ctx, lap ? "final_gather" : "weighted_gather");
         if (P->cn == 3 || P->cn == 1) {
-            const int nbx = (P->canvas_w + 255) / 256, edge_rows = (P->n_edge_blocks + nbx - 1) / nbx;
-            dim3 grid(nbx, edge_rows + (rows + 7) / 8);
+            const int nbx_r = std::max((P->canvas_w + FIN_BW - 1) / FIN_BW, 1), nby_r = std::max((rows + FIN_BH - 1) / FIN_BH, 1);
+            dim3 grid((unsigned)(P->n_edge_blocks + (long long)nbx_r * nby_r));     // edge blocks first, then the regular ones
 #define LAUNCH_BLK(DT, LAPV, CNV)                                                                               \
     hipLaunchKernelGGL((k_final_fast<DT, LAPV, CNV>), grid, block, 0, ctx->stream, P->d_fdesc, P->d_cand_off,     \
-                       P->d_cand_idx, P->d_edge_blocks, P->d_edge_cand, P->n_edge_blocks, edge_rows, P->d_arena, \
+                       P->d_cand_idx, P->d_edge_blocks, P->d_edge_cand, P->n_edge_blocks, nbx_r, P->d_arena, \
                        P->d_luts, d_canvas, (long long)canvas_stride, d_canvas_f32, P->canvas_w, P->row_begin,   \
                        P->row_end)
             if (P->cn == 3) {

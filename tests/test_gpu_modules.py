@@ -499,3 +499,29 @@ def test_detect_seams(rng):
     assert b0.detect_seams(result, infos) == []
     assert len(bm.BlendingModule(ssim_threshold=0.9).detect_seams(result[:96, :120], [tiles[0]])) == \
         len(onp.detect_seams(result[:96, :120], [tiles[0]], [(0, 0)], 0.9, 16, 8))
+
+
+def test_rccl_world1_smoke():
+    """The only RCCL exercise a one-GPU box allows (RCCL refuses two ranks on one device): a world-size-1 process group
+    on backend "nccl" with device_id, as bench.py / DevicePipeline create it -- communicator creation, the 4-double
+    metric all-reduce, an (empty-peer) grouped point-to-point batch and a barrier must work with this image's RCCL and
+    HSA_ENABLE_IPC_MODE_LEGACY=0.  Runs in a child process so the test process never owns a process group."""
+    import subprocess
+    import sys
+    code = r'''
+import os, torch, torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29631")
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+t = torch.tensor([1.5, 2.5, 3.5, 4.5], dtype=torch.float64, device=dev)
+w = dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True); w.wait()
+dist.barrier()
+torch.cuda.synchronize()
+assert t.tolist() == [1.5, 2.5, 3.5, 4.5]
+dist.destroy_process_group()
+print("rccl-ok")
+'''
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and "rccl-ok" in r.stdout, r.stderr[-2000:]

@@ -39,13 +39,17 @@ tile_px, canvas_px = bench["config"]["tile_pixels"], bench["config"]["canvas_pix
 known_read = 3.0 * tile_px                      # k_tile_extract reads exactly the tile pixels once
 cal = known_read / (fetch["k_tile_extract"] * 1024.0) if fetch.get("k_tile_extract") else 2.0
 out = {"unit": "bytes per bench step (all launches of the kernel)", "fetch_calibration_factor": cal,
-       "note": "read = FETCH_SIZE*1024*factor (factor calibrated on k_tile_extract, a pure copy); write = WRITE_SIZE*1024",
+       "note": "read = FETCH_SIZE*1024*factor with the factor calibrated on k_tile_extract (a pure copy of known size), "
+               "read_2x = FETCH_SIZE*1024*2 (the guide's correction for 16-B-per-lane streams; an upper bound for the "
+               "12-byte and byte-aligned loads used here); write = WRITE_SIZE*1024; total uses the calibrated read, "
+               "total_2x the guide's",
        "kernels": {}}
 for k in sorted(set(fetch) | set(write)):
     if not k.startswith("k_"):
         continue
-    rd, wr = fetch.get(k, 0.0) * 1024.0 * cal, write.get(k, 0.0) * 1024.0
-    out["kernels"][k] = {"read": rd, "write": wr, "total": rd + wr}
+    raw = fetch.get(k, 0.0) * 1024.0
+    rd, wr = raw * cal, write.get(k, 0.0) * 1024.0
+    out["kernels"][k] = {"read": rd, "read_2x": raw * 2.0, "write": wr, "total": rd + wr, "total_2x": raw * 2.0 + wr}
 json.dump(out, open(f"profiles/{prefix}_traffic.json", "w"), indent=1)
 # the bench line of this collection was printed before this summary existed: point its roofline at these counters
 roof = bench.get("roofline") or {}
