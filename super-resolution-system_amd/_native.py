@@ -760,7 +760,7 @@ class LpipsModel:
         check(self.ctx.lib.sr_lpips_tile_count(int(h), int(w), int(tile), C.byref(n)))
         return n.value
 
-    def layer_sums(self, d_a: int, stride_a: int, d_b: int, stride_b: int, h: int, w: int, cn: int, tile: int = 2048,
+    def layer_sums(self, d_a: int, stride_a: int, d_b: int, stride_b: int, h: int, w: int, cn: int, tile: int = 4096,
                    tile_begin: int = 0, tile_end: int = -1):
         """Per-tap sums of the lin maps over tiles [tile_begin, tile_end) (additive across disjoint tile ranges)."""
         out = (C.c_double * 5)()
@@ -768,7 +768,7 @@ class LpipsModel:
                                        int(w), int(cn), int(tile), int(tile_begin), int(tile_end), out))
         return [out[i] for i in range(5)]
 
-    def value(self, d_a: int, stride_a: int, d_b: int, stride_b: int, h: int, w: int, cn: int, tile: int = 2048,
+    def value(self, d_a: int, stride_a: int, d_b: int, stride_b: int, h: int, w: int, cn: int, tile: int = 4096,
               per_layer: bool = False):
         sums = self.layer_sums(d_a, stride_a, d_b, stride_b, h, w, cn, tile)
         vals = [s / (lh * lw) for s, (lh, lw) in zip(sums, self.layer_sizes(h, w))]

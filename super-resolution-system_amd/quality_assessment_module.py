@@ -114,7 +114,7 @@ class _DevImage:
 class QualityAssessmentModule:
     def __init__(self, device: str = 'cpu', thresholds: Optional[QualityThresholds] = None,
                  scale_config: Optional[ScaleConfig] = None, gpu_index: int = 0, ssim_branch: str = 'A',
-                 gray_shift: int = 15, lpips_weights: Optional[Dict[str, Any]] = None, lpips_tile: int = 2048):
+                 gray_shift: int = 15, lpips_weights: Optional[Dict[str, Any]] = None, lpips_tile: int = 4096):
         # the reference's `device` only places the LPIPS networks; the metrics here always run on the GPU
         self.device = device
         self.thresholds = thresholds or QualityThresholds()
