@@ -163,6 +163,56 @@ SR_API int sr_strip_tile_rows(const sr_tile_rect *h_tiles, int n, int levels, in
 /* Analytic worst case of that back-propagation (host only): a strip reads at most *below input rows before and *above
  * rows after its own rows of a tile (levels of >= 8 rows; 6 levels: 155 / 125). */
 SR_API int sr_pyramid_halo(int levels, int *below, int *above);
+/* Multi-GPU planning for a non-Python host (host only, deterministic, identical on every rank).
+ * sr_strip_bounds: world + 1 even row boundaries of horizontal canvas strips of equal work (assessment + gather of the
+ * strip's rows, pyramids of its rows plus the sr_pyramid_halo recompute).  sr_exchange_plan: the same bounds, per rank the
+ * canvas rows it blends h_rows[2 r .. 2 r + 1] (strip + metric_halo rows for the SSIM windows), the tile-local rows it
+ * needs of every tile h_need[(r * n + t) * 2 ..] (empty: [0, 0)) and an owner per tile.  Rank o sends rank r the rows
+ * h_need[r][t] of every tile t it owns (one grouped batch of point-to-point transfers; in the order (r, t) on the sender
+ * and (owner, t) on the receiver); the strip owner then calls sr_blend_plan_create(..., row_begin, row_end) with virtual
+ * tile base pointers.  Policies: balanced = greedy minimisation of the busiest rank-to-rank link (xGMI is point-to-point). */
+enum sr_owner_policy { SR_OWNER_BALANCED = 0, SR_OWNER_ROUNDROBIN = 1, SR_OWNER_LOCALITY = 2 };
+SR_API int sr_strip_bounds(const sr_tile_rect *h_tiles, int n, int levels, int canvas_h, int canvas_w, int world,
+                           int *h_bounds);
+SR_API int sr_exchange_plan(const sr_tile_rect *h_tiles, int n, int cn, int levels, int canvas_h, int canvas_w, int world,
+                            int metric_halo, int owner_policy, int *h_bounds, int *h_rows, int *h_need, int *h_owner);
+/* The transfers (csrc/sr_comm.cpp).  SURVEY 8(b) planned sr_comm_init + a sharded blend: one process per GPU, RCCL over
+ * xGMI.  No reference counterpart.  librccl.so is bound at run time (the copy the process already holds -- PyTorch's --
+ * else ROCm's; SR_RCCL_LIB overrides); without it these return SR_ERR_UNSUPPORTED, RCCL failures are SR_ERR_COMM.
+ *   rank 0: sr_comm_unique_id(id) -> the host ships the 128 bytes to every rank (MPI, a socket, a file) ->
+ *   every rank: sr_comm_init(ctx, id, world, rank, &comm)  [collective: ncclCommInitRank on ctx's device]
+ *   per image: sr_exchange_plan(...) once per geometry, then sr_comm_exchange_tile_rows(...) on ctx's stream, then
+ *   sr_blend_plan_create(row_begin, row_end) + the blend + metrics on the strip, sr_comm_allreduce_f64 of the 4 partial sums.
+ * sr_comm_wrap adopts an ncclComm_t the host created itself (not destroyed by sr_comm_destroy).
+ * sr_comm_exchange: ONE ncclGroupStart/End around the sends and receives (u8 bytes), so pairs that send to each other
+ * cannot deadlock; asynchronous on ctx's stream.  sr_comm_exchange_tile_rows builds that batch from the plan: rank `me`
+ * sends rows h_need[r][t] of every tile t it owns (d_owned[t], DENSE rows of w * cn bytes) to every other rank r that needs
+ * them, and receives rows h_need[me][t] of the tiles others own into d_recv[t] (a dense buffer of (r1 - r0) * w * cn bytes;
+ * the blend then takes d_recv[t] - r0 * w * cn as the tile's virtual base pointer).  u8 tiles only. */
+#define SR_COMM_ID_BYTES 128
+typedef struct sr_comm sr_comm;
+typedef struct sr_xfer {
+    int peer;
+    void *d_ptr;
+    uint64_t bytes;
+} sr_xfer;
+SR_API int sr_comm_unique_id(void *id128);
+SR_API int sr_comm_init(sr_ctx *ctx, const void *id128, int world, int rank, sr_comm **out);
+SR_API int sr_comm_wrap(void *nccl_comm, sr_comm **out);
+SR_API int sr_comm_info(const sr_comm *comm, int *world, int *rank);
+SR_API int sr_comm_destroy(sr_comm *comm);
+SR_API int sr_comm_exchange(sr_ctx *ctx, sr_comm *comm, const sr_xfer *sends, int n_send, const sr_xfer *recvs, int n_recv);
+SR_API int sr_comm_exchange_tile_rows(sr_ctx *ctx, sr_comm *comm, const sr_tile_rect *h_tiles, int n, int cn,
+                                      const int *h_need, const int *h_owner, const void *const *d_owned,
+                                      const int64_t *owned_stride, void *const *d_recv);
+/* host only: the batch sr_comm_exchange_tile_rows posts, for hosts that move the rows themselves (MPI, hipMemcpyPeer).
+ * Sends in (reader, tile) order, receives in (owner, tile) order; *n_send / *n_recv are the counts needed (SR_ERR_SHAPE when
+ * the arrays are too small: at most n * (world - 1) sends and n receives). */
+SR_API int sr_exchange_xfers(const sr_tile_rect *h_tiles, int n, int cn, int world, int rank, const int *h_need,
+                             const int *h_owner, const void *const *d_owned, const int64_t *owned_stride,
+                             void *const *d_recv, sr_xfer *sends, int cap_send, int *n_send, sr_xfer *recvs, int cap_recv,
+                             int *n_recv);
+SR_API int sr_comm_allreduce_f64(sr_ctx *ctx, sr_comm *comm, double *d_buf, int count);
 /* tile-local rows [*r0, *r1) of tile t that the plan reads (empty if r0 >= r1): what a strip
  * owner must hold / receive for that tile. */
 SR_API int sr_blend_plan_tile_rows(const sr_blend_plan *plan, int t, int *r0, int *r1);

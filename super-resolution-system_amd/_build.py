@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libsrhip.so")
 OBJ_DIR = os.path.join(_HERE, "build")
 SOURCES = [os.path.join(CSRC, n) for n in ("sr_engine.hip", "sr_lpips.hip", "sr_adjust.hip", "sr_encode.cpp",
-                                           "sr_host.cpp")]
+                                           "sr_comm.cpp", "sr_host.cpp")]
 HEADERS = [os.path.join(CSRC, "sr_internal.h"), os.path.join(CSRC, "sr_ctx.h"),
            os.path.join(_ROOT, "include", "sr_hip.h")]
 
@@ -78,7 +78,7 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=min(4, max(len(jobs), 1))) as ex:
         list(ex.map(run, jobs))
-    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden", "-o", LIB] + objs + ["-lpthread", "-lz"])
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden", "-o", LIB] + objs + ["-lpthread", "-lz", "-ldl"])
     with open(DIGEST_FILE, "w") as f:
         f.write(digest + "\n")
     return LIB

@@ -30,6 +30,10 @@ class SrShapeError(ValueError):
     """SR_ERR_SHAPE: the reference raises cv2.error / ValueError for these."""
 
 
+class Xfer(C.Structure):
+    _fields_ = [("peer", C.c_int), ("d_ptr", C.c_void_p), ("bytes", C.c_uint64)]
+
+
 class TileRect(C.Structure):
     _fields_ = [("x", C.c_int), ("y", C.c_int), ("w", C.c_int), ("h", C.c_int)]
 
@@ -95,6 +99,19 @@ SIGNATURES = {
     "sr_blend_plan_destroy": (_i, [_vp]),
     "sr_strip_tile_rows": (_i, [C.POINTER(TileRect), _i, _i, _i, _i, _i, _pi]),
     "sr_pyramid_halo": (_i, [_i, _pi, _pi]),
+    "sr_comm_unique_id": (_i, [_vp]),
+    "sr_comm_init": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
+    "sr_comm_wrap": (_i, [_vp, C.POINTER(_vp)]),
+    "sr_comm_info": (_i, [_vp, _pi, _pi]),
+    "sr_comm_destroy": (_i, [_vp]),
+    "sr_comm_exchange": (_i, [_vp, _vp, C.POINTER(Xfer), _i, C.POINTER(Xfer), _i]),
+    "sr_comm_exchange_tile_rows": (_i, [_vp, _vp, C.POINTER(TileRect), _i, _i, _pi, _pi, C.POINTER(_vp), C.POINTER(_i64),
+                                        C.POINTER(_vp)]),
+    "sr_comm_allreduce_f64": (_i, [_vp, _vp, _vp, _i]),
+    "sr_exchange_xfers": (_i, [C.POINTER(TileRect), _i, _i, _i, _i, _pi, _pi, C.POINTER(_vp), C.POINTER(_i64), C.POINTER(_vp),
+                               C.POINTER(Xfer), _i, _pi, C.POINTER(Xfer), _i, _pi]),
+    "sr_strip_bounds": (_i, [C.POINTER(TileRect), _i, _i, _i, _i, _i, _pi]),
+    "sr_exchange_plan": (_i, [C.POINTER(TileRect), _i, _i, _i, _i, _i, _i, _i, _i, _pi, _pi, _pi, _pi]),
     "sr_blend_plan_tile_rows": (_i, [_vp, _i, _pi, _pi]),
     "sr_blend_plan_workspace_bytes": (_i, [_vp, C.POINTER(_sz)]),
     "sr_laplacian_blend": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_i64), _vp, _i64, _vp]),
@@ -155,6 +172,27 @@ def _preload_hip_runtime() -> None:
     if os.path.exists(cand):
         try:
             C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
+def _preload_rccl() -> None:
+    """One RCCL per process, and the one PyTorch was built against: libtorch_hip.so needs "librccl.so" and would adopt
+    whichever copy the process already holds, so before sr_comm.cpp binds RCCL (dlopen; a held copy wins) the wheel's own
+    copy is loaded by path.  Without torch installed the ROCm copy is used.  RTLD_LOCAL on purpose: librccl.so drags in
+    librocm_smi64.so, whose statics libamd_smi.so (loaded later by torch's device queries) re-defines -- with the symbols
+    global both copies destroyed the same objects at exit (double free, seen in the full GPU suite)."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "librccl.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand)
         except OSError:
             pass
 
@@ -278,6 +316,34 @@ def write_image(arr: np.ndarray, path: str, threads: int = 0, png_level: int = 3
         raise ValueError("cannot write an RGBA image as JPEG")       # Pillow raises OSError here
     check(lib.sr_encode_jpeg(ptr, h, w, cn, w * cn, jpeg_quality, p, threads))
     return "JPEG"
+
+
+OWNER_POLICIES = {"balanced": 0, "roundrobin": 1, "locality": 2}
+
+
+def _rects(rects_xywh):
+    n = len(rects_xywh)
+    return n, (TileRect * max(n, 1))(*[TileRect(int(x), int(y), int(w), int(h)) for (x, y, w, h) in rects_xywh])
+
+
+def strip_bounds(rects_xywh, levels: int, canvas_h: int, canvas_w: int, world: int) -> List[int]:
+    """Host-only: work-balanced, even strip boundaries (sr_strip_bounds)."""
+    n, rects = _rects(rects_xywh)
+    out = (C.c_int * (world + 1))()
+    check(load().sr_strip_bounds(rects, n, int(levels), int(canvas_h), int(canvas_w), int(world), out))
+    return list(out)
+
+
+def exchange_plan(rects_xywh, cn: int, levels: int, canvas_h: int, canvas_w: int, world: int, metric_halo: int,
+                  owner_policy: str = "balanced"):
+    """Host-only: (bounds, rows per rank, need[r][t] = (r0, r1), owners) of the strip exchange (sr_exchange_plan)."""
+    n, rects = _rects(rects_xywh)
+    bounds, rows = (C.c_int * (world + 1))(), (C.c_int * (2 * world))()
+    need, owner = (C.c_int * (2 * world * n))(), (C.c_int * n)()
+    check(load().sr_exchange_plan(rects, n, int(cn), int(levels), int(canvas_h), int(canvas_w), int(world), int(metric_halo),
+                                  OWNER_POLICIES[owner_policy], bounds, rows, need, owner))
+    return (list(bounds), [(rows[2 * r], rows[2 * r + 1]) for r in range(world)],
+            [[(need[(r * n + t) * 2], need[(r * n + t) * 2 + 1]) for t in range(n)] for r in range(world)], list(owner))
 
 
 def pyramid_halo(levels: int) -> Tuple[int, int]:
@@ -602,6 +668,71 @@ def _feather_merge_np(self, arrays, descs, output_width: int, output_height: int
 
 
 Context.feather_merge_np = _feather_merge_np
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """sr_comm_unique_id: the 128-byte rendezvous token rank 0 creates and ships to every rank."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _preload_rccl()
+    check(load().sr_comm_unique_id(buf))
+    return buf.raw
+
+
+def _xfer_args(rects_xywh, world, need, owners, owned_ptrs, owned_strides, recv_ptrs):
+    n, rects = _rects(rects_xywh)
+    flat = (C.c_int * (2 * world * n))(*[v for r in range(world) for t in range(n) for v in need[r][t]])
+    own = (C.c_int * n)(*[int(o) for o in owners])
+    dp = (_vp * n)(*[int(p) if p else None for p in owned_ptrs])
+    st = (_i64 * n)(*[int(v) for v in owned_strides])
+    rp = (_vp * n)(*[int(p) if p else None for p in recv_ptrs])
+    return n, rects, flat, own, dp, st, rp
+
+
+def exchange_xfers(rects_xywh, cn: int, world: int, rank: int, need, owners, owned_ptrs, owned_strides, recv_ptrs):
+    """Host-only (sr_exchange_xfers): ([(peer, pointer, bytes)] sends, receives) of one rank's grouped exchange."""
+    n, rects, flat, own, dp, st, rp = _xfer_args(rects_xywh, world, need, owners, owned_ptrs, owned_strides, recv_ptrs)
+    sends, recvs = (Xfer * (n * world))(), (Xfer * n)()
+    ns, nr = C.c_int(0), C.c_int(0)
+    check(load().sr_exchange_xfers(rects, n, int(cn), int(world), int(rank), flat, own, dp, st, rp, sends, n * world, C.byref(ns),
+                                   recvs, n, C.byref(nr)))
+    return ([(sends[i].peer, sends[i].d_ptr or 0, sends[i].bytes) for i in range(ns.value)],
+            [(recvs[i].peer, recvs[i].d_ptr or 0, recvs[i].bytes) for i in range(nr.value)])
+
+
+class Comm:
+    """RCCL communicator of the C ABI (sr_comm_*): one process per GPU, transfers on the context's stream."""
+
+    def __init__(self, ctx: "Context", unique_id: bytes, world: int, rank: int):
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError("unique_id must be the 128 bytes of comm_unique_id()")
+        self.ctx, self.world, self.rank = ctx, int(world), int(rank)
+        h = _vp()
+        _preload_rccl()
+        check(load().sr_comm_init(ctx.handle, C.create_string_buffer(unique_id, COMM_ID_BYTES), self.world, self.rank, C.byref(h)))
+        self.h = h
+
+    def exchange(self, sends, recvs):
+        """sends / recvs: [(peer, device pointer, bytes)] -- one grouped batch, asynchronous on the context's stream."""
+        s = (Xfer * max(len(sends), 1))(*[Xfer(int(p), int(d), int(b)) for (p, d, b) in sends])
+        r = (Xfer * max(len(recvs), 1))(*[Xfer(int(p), int(d), int(b)) for (p, d, b) in recvs])
+        check(load().sr_comm_exchange(self.ctx.handle, self.h, s, len(sends), r, len(recvs)))
+
+    def exchange_tile_rows(self, rects_xywh, cn: int, need, owners, owned_ptrs, owned_strides, recv_ptrs):
+        """sr_comm_exchange_tile_rows: need[r][t] = (r0, r1) and owners from exchange_plan(); owned_ptrs[t] / recv_ptrs[t]
+        are device pointers or 0."""
+        n, rects, flat, own, dp, st, rp = _xfer_args(rects_xywh, self.world, need, owners, owned_ptrs, owned_strides, recv_ptrs)
+        check(load().sr_comm_exchange_tile_rows(self.ctx.handle, self.h, rects, n, int(cn), flat, own, dp, st, rp))
+
+    def allreduce_f64(self, d_ptr: int, count: int):
+        check(load().sr_comm_allreduce_f64(self.ctx.handle, self.h, _vp(int(d_ptr)), int(count)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            h, self.h = self.h, None
+            check(load().sr_comm_destroy(h))
 
 
 class BlendPlan:

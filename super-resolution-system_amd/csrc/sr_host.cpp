@@ -5,6 +5,7 @@
 #include <cstring>
 #include <map>
 #include <utility>
+#include <vector>
 
 #include "sr_internal.h"
 
@@ -168,6 +169,138 @@ int sr_pyramid_halo(int levels, int *below, int *above)
     *below = (int)((5 * p) / 2 - 5);
     *above = (int)(2 * p - 3);
     if (levels == 1) *below = *above = 0;
+    return SR_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Multi-GPU planning (host only, identical on every rank): the canvas is cut into `world` horizontal
+// strips of equal WORK, every tile gets an owner, and sr_exchange_plan lists, per rank, the tile rows it must hold --
+// what an owner sends and a strip owner receives.  The transfers themselves belong to the host (RCCL ncclSend /
+// ncclRecv in one group, MPI, hipMemcpyPeer ...); device_pipeline.py posts them through torch.distributed.
+// ---------------------------------------------------------------------------------------------------------------
+// Relative cost of the stages per pixel, from the per-kernel times at 200 MP on MI355X (ps per pixel): what a canvas
+// row costs its strip owner.  Only the ratios matter.
+static const double COST_ASSESS = 10.5;    // per canvas pixel (fused PSNR + 3 x SSIM)
+static const double COST_GATHER = 4.0;     // per tile pixel visited by the canvas gather
+static const double COST_PYRAMID = 6.6;    // per tile pixel of the pyramid chains -- also paid for the halo rows
+
+int sr_strip_bounds(const sr_tile_rect *h_tiles, int n, int levels, int canvas_h, int canvas_w, int world, int *h_bounds)
+{
+    if (!h_bounds || world < 1 || canvas_h < 1 || canvas_w < 1 || n < 0 || (n > 0 && !h_tiles) || levels < 1)
+        return sr_set_error(SR_ERR_INVALID_ARG, "sr_strip_bounds: bad arguments");
+    if (world == 1 || n == 0) {
+        for (int r = 0; r <= world; ++r) h_bounds[r] = (int)((long long)canvas_h * r / world);
+        return SR_OK;
+    }
+    int below = 0, above = 0;
+    sr_pyramid_halo(std::min(levels, SR_MAX_LEVELS), &below, &above);
+    const int halo = std::max(below, above);
+    std::vector<double> cover((size_t)canvas_h, 0.0), cum_can((size_t)canvas_h + 1, 0.0), cum_pyr((size_t)canvas_h + 1, 0.0);
+    for (int t = 0; t < n; ++t) {
+        const sr_tile_rect &r = h_tiles[t];
+        for (int y = std::max(r.y, 0); y < std::min(r.y + r.h, canvas_h); ++y) cover[(size_t)y] += r.w;
+    }
+    for (int y = 0; y < canvas_h; ++y) {
+        cum_can[(size_t)y + 1] = cum_can[(size_t)y] + (COST_ASSESS * canvas_w + COST_GATHER * cover[(size_t)y]);
+        cum_pyr[(size_t)y + 1] = cum_pyr[(size_t)y] + COST_PYRAMID * cover[(size_t)y];
+    }
+    // a strip [a, b) costs the assessment and gather work of its own rows plus the pyramid work of rows a - halo ..
+    // b + halo (clipped: the outer strips recompute a halo on one side only)
+    auto cost = [&](int a, int b) {
+        const int lo = std::max(a - halo, 0), hi = std::min(b + halo, canvas_h);
+        return cum_can[(size_t)b] - cum_can[(size_t)a] + cum_pyr[(size_t)hi] - cum_pyr[(size_t)lo];
+    };
+    auto place = [&](double target, std::vector<int> &bounds) {
+        bounds.assign(1, 0);
+        for (int k = 0; k + 1 < world; ++k) {
+            const int a = bounds.back();
+            int lo = a + 2, hi = canvas_h;                     // smallest even b with cost(a, b) >= target
+            while (lo < hi) {
+                const int mid = (lo + hi) / 2;
+                if (cost(a, std::min(mid, canvas_h)) >= target) hi = mid;
+                else lo = mid + 1;
+            }
+            const int b = std::min(lo + (lo % 2), canvas_h);
+            bounds.push_back(std::max(b, std::min(a + 2, canvas_h)));
+        }
+        bounds.push_back(canvas_h);
+    };
+    double t_lo = 0.0, t_hi = cost(0, canvas_h);
+    std::vector<int> bnd;
+    for (int it = 0; it < 60; ++it) {                          // bisection on the per-strip cost: the last strip absorbs the rest
+        const double t = 0.5 * (t_lo + t_hi);
+        place(t, bnd);
+        if (cost(std::min(bnd[(size_t)world - 1], canvas_h), canvas_h) > t) t_lo = t;
+        else t_hi = t;
+    }
+    place(t_hi, bnd);
+    for (int r = 1; r <= world; ++r) bnd[(size_t)r] = std::min(std::max(bnd[(size_t)r], bnd[(size_t)r - 1]), canvas_h);
+    for (int r = 0; r <= world; ++r) h_bounds[r] = bnd[(size_t)r];
+    return SR_OK;
+}
+
+int sr_exchange_plan(const sr_tile_rect *h_tiles, int n, int cn, int levels, int canvas_h, int canvas_w, int world,
+                     int metric_halo, int owner_policy, int *h_bounds, int *h_rows, int *h_need, int *h_owner)
+{
+    if (!h_tiles || !h_bounds || !h_rows || !h_need || !h_owner || n < 1 || world < 1 || cn < 1 || levels < 1 || metric_halo < 0 ||
+        owner_policy < 0 || owner_policy > 2)
+        return sr_set_error(SR_ERR_INVALID_ARG, "sr_exchange_plan: bad arguments");
+    int rc = sr_strip_bounds(h_tiles, n, levels, canvas_h, canvas_w, world, h_bounds);
+    if (rc) return rc;
+    for (int r = 0; r < world; ++r) {
+        const int a = std::max(h_bounds[r] - (world > 1 ? metric_halo : 0), 0);
+        const int b = std::min(h_bounds[r + 1] + (world > 1 ? metric_halo : 0), canvas_h);
+        h_rows[2 * r] = a;
+        h_rows[2 * r + 1] = b;
+        rc = sr_strip_tile_rows(h_tiles, n, levels, canvas_h, a, b, h_need + (size_t)r * n * 2);
+        if (rc) return rc;
+    }
+    if (owner_policy == SR_OWNER_ROUNDROBIN) {
+        for (int t = 0; t < n; ++t) h_owner[t] = t % world;
+        return SR_OK;
+    }
+    if (owner_policy == SR_OWNER_LOCALITY) {                   // the rank whose strip holds the tile's centre row
+        for (int t = 0; t < n; ++t) {
+            const int c = std::min(h_tiles[t].y + h_tiles[t].h / 2, h_bounds[world] - 1);
+            int o = 0;
+            while (o + 1 < world && h_bounds[o + 1] <= c) ++o;
+            h_owner[t] = o;
+        }
+        return SR_OK;
+    }
+    // SR_OWNER_BALANCED: greedy, tile by tile, the owner that minimises the busiest rank-to-rank link after the assignment,
+    // then the bytes added, then the owner's tile count (xGMI is point-to-point: the heaviest pair bounds the exchange)
+    std::vector<long long> link((size_t)world * world, 0);
+    std::vector<int> owned((size_t)world, 0);
+    long long link_max = 0;
+    for (int t = 0; t < n; ++t) {
+        std::vector<long long> nbytes((size_t)world);
+        for (int r = 0; r < world; ++r) {
+            const int *nd = h_need + ((size_t)r * n + t) * 2;
+            nbytes[(size_t)r] = (long long)std::max(nd[1] - nd[0], 0) * h_tiles[t].w * cn;
+        }
+        int best_o = -1;
+        long long best_worst = 0, best_sum = 0;
+        for (int o = 0; o < world; ++o) {
+            long long worst = link_max, sum = 0;
+            for (int r = 0; r < world; ++r) {
+                const long long add = r == o ? 0 : nbytes[(size_t)r];
+                worst = std::max(worst, link[(size_t)o * world + r] + add);
+                sum += add;
+            }
+            const bool better = best_o < 0 || worst < best_worst || (worst == best_worst && (sum < best_sum ||
+                                (sum == best_sum && owned[(size_t)o] < owned[(size_t)best_o])));
+            if (better) { best_o = o; best_worst = worst; best_sum = sum; }
+        }
+        for (int r = 0; r < world; ++r)
+            if (r != best_o) {
+                link[(size_t)best_o * world + r] += nbytes[(size_t)r];
+                link_max = std::max(link_max, link[(size_t)best_o * world + r]);
+            }
+        owned[(size_t)best_o] += 1;
+        h_owner[t] = best_o;
+    }
     return SR_OK;
 }
 
