@@ -74,44 +74,64 @@ bool write_file(const char *path, const std::vector<const std::vector<uint8_t> *
 // TIFF 6.0, LZW (compression 5), no predictor, 8-bit samples, chunky
 // ------------------------------------------------------------------------------------------------------------------
 struct LzwTable {
-    // open-addressed hash of (prefix code, byte) -> code; 4096 codes at most
-    static constexpr int HSIZE = 9001;
-    int key[HSIZE];
-    short val[HSIZE];
-    void clear() { std::fill(key, key + HSIZE, -1); }
+    // open-addressed hash of (prefix code, byte) -> code; 4096 codes at most in 16384 slots.  A slot is
+    // generation << 20 | prefix << 8 | byte: a CLEAR code bumps the generation instead of wiping 64 KB (on photographic
+    // data the table fills every ~6 KB of input, so wiping it cost more than the coding itself).
+    static constexpr int HBITS = 14, HSIZE = 1 << HBITS;
+    uint32_t key[HSIZE];
+    uint16_t val[HSIZE];
+    uint32_t gen = 0;
+    LzwTable() { std::fill(key, key + HSIZE, 0u); }
+    void clear()
+    {
+        if (++gen == (1u << 12)) {              // generation field exhausted: really wipe
+            std::fill(key, key + HSIZE, 0u);
+            gen = 1;
+        }
+    }
 };
 
 void lzw_encode_strip(const uint8_t *src, size_t n, std::vector<uint8_t> &out, LzwTable &tab)
 {
     const int CLEAR = 256, EOI = 257;
-    uint32_t acc = 0;
+    // worst case 12 bits per input byte plus the CLEAR codes (one per 3836 codes) and CLEAR / EOI / padding
+    out.resize(n + n / 2 + n / 2048 + 16);
+    uint8_t *dst = out.data();
+    uint64_t acc = 0;                           // MSB-first bit buffer: the nbits valid bits are its low bits
     int nbits = 0, width = 9, next = 258;
     auto put = [&](int code) {
-        acc = (acc << width) | (uint32_t)code;
+        acc = (acc << width) | (uint64_t)(unsigned)code;
         nbits += width;
-        while (nbits >= 8) {
-            out.push_back((uint8_t)(acc >> (nbits - 8)));
-            nbits -= 8;
+        if (nbits >= 32) {                      // flush four bytes at a time
+            const uint32_t w = (uint32_t)(acc >> (nbits - 32));
+            dst[0] = (uint8_t)(w >> 24); dst[1] = (uint8_t)(w >> 16); dst[2] = (uint8_t)(w >> 8); dst[3] = (uint8_t)w;
+            dst += 4;
+            nbits -= 32;
         }
-        acc &= (1u << nbits) - 1u;
+    };
+    auto finish = [&]() {
+        while (nbits >= 8) { *dst++ = (uint8_t)(acc >> (nbits - 8)); nbits -= 8; }
+        if (nbits) *dst++ = (uint8_t)(acc << (8 - nbits));
+        out.resize((size_t)(dst - out.data()));
     };
     tab.clear();
     put(CLEAR);
-    if (n == 0) { put(EOI); if (nbits) out.push_back((uint8_t)(acc << (8 - nbits))); return; }
+    if (n == 0) { put(EOI); finish(); return; }
+    uint32_t tag = tab.gen << 20;
     int prefix = src[0];
     for (size_t i = 1; i < n; ++i) {
         const int c = src[i];
-        const int k = (prefix << 8) | c;
-        int h = (int)(((unsigned)k * 2654435761u) % LzwTable::HSIZE);
+        const uint32_t k = tag | ((uint32_t)prefix << 8) | (uint32_t)c;
+        uint32_t h = (((uint32_t)prefix << 8 | (uint32_t)c) * 2654435761u) >> (32 - LzwTable::HBITS);
         int found = -1;
-        while (tab.key[h] != -1) {
+        while ((tab.key[h] >> 20) == tab.gen) {             // a slot of an older generation is empty
             if (tab.key[h] == k) { found = tab.val[h]; break; }
-            if (++h == LzwTable::HSIZE) h = 0;
+            h = (h + 1) & (LzwTable::HSIZE - 1);
         }
         if (found >= 0) { prefix = found; continue; }
         put(prefix);
         tab.key[h] = k;
-        tab.val[h] = (short)next++;
+        tab.val[h] = (uint16_t)next++;
         // "early change" (TIFF 6.0 section 13, libtiff's rule): the width grows as soon as entry 511 / 1023 / 2047 has been
         // added -- one entry before a plain LZW would need it; the table is cleared once entry 4093 has been added
         if (next == 512) width = 10;
@@ -120,6 +140,7 @@ void lzw_encode_strip(const uint8_t *src, size_t n, std::vector<uint8_t> &out, L
         else if (next == 4094) {
             put(CLEAR);
             tab.clear();
+            tag = tab.gen << 20;
             next = 258;
             width = 9;
         }
@@ -133,7 +154,7 @@ void lzw_encode_strip(const uint8_t *src, size_t n, std::vector<uint8_t> &out, L
     else if (next == 1024) width = 11;
     else if (next == 2048) width = 12;
     put(EOI);
-    if (nbits) out.push_back((uint8_t)(acc << (8 - nbits)));
+    finish();
 }
 
 void put16(std::vector<uint8_t> &v, uint16_t x) { v.push_back((uint8_t)(x & 255)); v.push_back((uint8_t)(x >> 8)); }
