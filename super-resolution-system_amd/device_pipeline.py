@@ -172,12 +172,26 @@ class _StagedWork:
             self.dev.copy_(self.host)
 
 
+def exchange_ops(plan: ExchangePlan, rank: int, local_tiles: Dict[int, "object"], recv_bufs: Dict[int, "object"], group=None):
+    """The P2POp list of one rank's exchange (sends in (reader, tile) order, receives in (owner, tile) order -- the order
+    sr_exchange_xfers lists them in).  The buffers of a set do not change between images, so a stream of images builds
+    this once per set and posts the same list every step."""
+    import torch.distributed as dist
+    ops = []
+    for (peer, t, a, b) in plan.sends(rank):
+        ops.append(dist.P2POp(dist.isend, local_tiles[t][a:b], peer, group))
+    for (peer, t, a, b) in plan.recvs(rank):
+        ops.append(dist.P2POp(dist.irecv, recv_bufs[t], peer, group))
+    return ops
+
+
 def exchange_tile_rows(plan: ExchangePlan, rank: int, local_tiles: Dict[int, "object"],
-                       recv_bufs: Dict[int, "object"], group=None):
+                       recv_bufs: Dict[int, "object"], group=None, ops=None):
     """Send the rows other strips need of the tiles this rank owns, receive the rows this strip
     needs of tiles owned elsewhere.  Tiles are 2-D uint8 tensors [h, w*cn]; recv_bufs[t] has exactly
     (r1 - r0) rows.  One grouped batch of point-to-point ops (ncclSend/ncclRecv under
-    ncclGroupStart/End on RCCL; plain isend/irecv on gloo).  Returns the work handles.
+    ncclGroupStart/End on RCCL; plain isend/irecv on gloo).  Returns the work handles.  ``ops``: a list from
+    exchange_ops() for these buffers (built here when not given).
 
     gloo cannot move device tensors point-to-point: with that backend and GPU tensors (the single-GPU rehearsal
     of the multi-rank path) rows are staged through host memory -- a test vehicle, never the measured path."""
@@ -194,11 +208,8 @@ def exchange_tile_rows(plan: ExchangePlan, rank: int, local_tiles: Dict[int, "ob
             host = recv_bufs[t].new_empty(recv_bufs[t].shape, device="cpu")
             works.append(_StagedWork(dist.irecv(host, peer, group=group, tag=t), host, recv_bufs[t]))
         return works
-    ops = []
-    for (peer, t, a, b) in sends:
-        ops.append(dist.P2POp(dist.isend, local_tiles[t][a:b], peer, group))
-    for (peer, t, a, b) in recvs:
-        ops.append(dist.P2POp(dist.irecv, recv_bufs[t], peer, group))
+    if ops is None:
+        ops = exchange_ops(plan, rank, local_tiles, recv_bufs, group)
     # One grouped batch (ncclGroupStart / End around every ncclSend / ncclRecv): inside a group NCCL matches the
     # transfers of a pair whatever their posting order, so two strips that send to each other cannot deadlock.  There is
     # deliberately no ungrouped fallback: posted one by one, each rank would queue its sends ahead of its receives on the
@@ -310,7 +321,12 @@ class DevicePipeline:
         """Posts the grouped sends / receives; returns the work handles (empty on one GPU)."""
         if self.world == 1:
             return []
-        return exchange_tile_rows(self.xplan, self.rank, self.sets[k]["local"], self.sets[k]["recv"], self.group)
+        st = self.sets[k]
+        if "ops" not in st:                                # same buffers every image: the op list is built once per set
+            import torch.distributed as dist
+            staged = dist.get_backend(self.group) == "gloo" and self.dev.type == "cuda"
+            st["ops"] = None if staged else exchange_ops(self.xplan, self.rank, st["local"], st["recv"], self.group)
+        return exchange_tile_rows(self.xplan, self.rank, st["local"], st["recv"], self.group, ops=st["ops"])
 
     def stage_blend(self, pending=(), k: int = 0, slot: int = 0):
         """Pyramids of the tiles this rank already holds run while the exchange is in flight; the tiles that
