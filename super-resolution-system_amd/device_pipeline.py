@@ -217,6 +217,38 @@ def exchange_tile_rows(plan: ExchangePlan, rank: int, local_tiles: Dict[int, "ob
     return dist.batch_isend_irecv(ops)
 
 
+def gather_strips(canvas, bounds: Sequence[int], rank: int, group=None, dst: int = 0):
+    """The final image, only when the caller asks for the array: every rank's canvas tensor [H, W*cn] holds
+    its own strip rows bounds[rank] .. bounds[rank + 1]; rank ``dst`` receives the other strips into its canvas (rows are
+    contiguous: one transfer per peer, one grouped batch) and returns it, the others send and return None.  With gloo
+    and GPU tensors (rehearsal) the rows are staged through host memory."""
+    import torch.distributed as dist
+    world = len(bounds) - 1
+    if world == 1:
+        return canvas
+    staged = canvas.is_cuda and dist.get_backend(group) == "gloo"
+    if rank != dst:
+        a, b = bounds[rank], bounds[rank + 1]
+        if a < b:
+            rows = canvas[a:b]
+            if staged:
+                dist.send(rows.cpu(), dst, group=group)
+            else:
+                for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, rows, dst, group)]):
+                    w.wait()
+        return None
+    peers = [(r, bounds[r], bounds[r + 1]) for r in range(world) if r != dst and bounds[r] < bounds[r + 1]]
+    if staged:
+        for (r, a, b) in peers:
+            host = canvas.new_empty((b - a, canvas.shape[1]), device="cpu")
+            dist.recv(host, r, group=group)
+            canvas[a:b].copy_(host)
+    elif peers:
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, canvas[a:b], r, group) for (r, a, b) in peers]):
+            w.wait()
+    return canvas
+
+
 # ---------------------------------------------------------------------------------------------
 # per-rank device pipeline
 # ---------------------------------------------------------------------------------------------
@@ -464,6 +496,13 @@ class DevicePipeline:
             self._reduce_work[j] = []
             if self._e_qa[j] is not None:
                 self.main_stream.wait_event(self._e_qa[j])
+
+    def gather_canvas(self, dst: int = 0):
+        """The whole blended image on rank ``dst`` (a device tensor [H, W*cn]; None elsewhere): the strips stay on their
+        GPUs unless this is called."""
+        self.pipeline_finish()
+        self.torch.cuda.current_stream(self.dev).synchronize()
+        return gather_strips(self.canvas, self.xplan.bounds, self.rank, self.group, dst)
 
     # -- single-process rehearsal of a rank (tests): same buffers, same staged kernels, no communicator ------------
     def rehearse_fill(self, full_tiles: Dict[int, "object"]):

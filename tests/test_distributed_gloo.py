@@ -67,7 +67,12 @@ def _worker(rank, world, port, q):
         dist.all_reduce(part)
         total = float(((ref.astype(np.int64) - full.astype(np.int64)) ** 2).sum())
         recv_bytes = xp.bytes_received(rank, geo)
-        q.put((rank, ok_rows, float(part.item()) == total, recv_bytes, None))
+        # the final image on request: every rank contributes exactly its strip, rank 0 ends up with the monolithic canvas
+        canvas = torch.full((geo.canvas_h, geo.canvas_w * 3), 0x77, dtype=torch.uint8)
+        canvas[s0:s1] = torch.from_numpy(mine[s0:s1].reshape(s1 - s0, -1))
+        whole = dp.gather_strips(canvas, xp.bounds, rank, None, dst=0)
+        ok_gather = (whole is None) if rank != 0 else bool(np.array_equal(whole.numpy().reshape(full.shape), full))
+        q.put((rank, ok_rows and ok_gather, float(part.item()) == total, recv_bytes, None))
     except Exception as exc:  # noqa: BLE001
         import traceback
         q.put((rank, False, False, 0, traceback.format_exc()))

@@ -504,8 +504,9 @@ def test_detect_seams(rng):
 def test_rccl_world1_smoke():
     """The only RCCL exercise a one-GPU box allows (RCCL refuses two ranks on one device): a world-size-1 process group
     on backend "nccl" with device_id, as bench.py / DevicePipeline create it -- communicator creation, the 4-double
-    metric all-reduce, an (empty-peer) grouped point-to-point batch and a barrier must work with this image's RCCL and
-    HSA_ENABLE_IPC_MODE_LEGACY=0.  Runs in a child process so the test process never owns a process group."""
+    metric all-reduce (async, as the pipeline posts it) and a barrier must work with this image's RCCL and
+    HSA_ENABLE_IPC_MODE_LEGACY=0 (torch refuses a send to the own rank, so the grouped ncclSend / ncclRecv batch is
+    exercised through the C ABI instead: tests/test_gpu_comm.py).  Runs in a child process so the test process never owns a process group."""
     import subprocess
     import sys
     code = r'''
