@@ -1642,7 +1642,8 @@ __device__ __forceinline__ double ssim_value(double ux, double uy, double spq, d
 #define AM_GP (AM_TX + 16)              /* row pitch in pixels: 10 halo columns, rounded up to groups of 4 */
 #define AM_CH 11                        /* rows per chunk == FIFO depth */
 #define AM_NCH_MAX 12                   /* chunks per block: P.nch <= 12, chosen per launch (rows / tail effect) */
-/* a block marches 11 * nch rows and produces P.ty = 11 * nch - 10 of them; LDS 36 KB + 14 KB ring -> 3 blocks per CU */
+/* a block marches 11 * nch rows and produces P.ty = 11 * nch - 10 of them; LDS 36 KB + 14 KB ring + 2 KB -> 3 blocks per CU */
+
 
 // cv2.resize(INTER_CUBIC) sample of one destination pixel (all channels) -- the arithmetic of k_resize_cubic
 template <int CN>
@@ -1687,13 +1688,14 @@ __device__ __forceinline__ void cubic_sample(const unsigned char *__restrict__ s
 // gray conversion + per-pixel products of 4-pixel groups of chunk `ch` into LDS; returns this thread's share of the
 // squared differences of the block's own pixels
 template <int CN, bool RESIZE>
-__device__ __forceinline__ unsigned long long assess_load_chunk(const unsigned char *__restrict__ a, long long sa,
-                                                                const unsigned char *__restrict__ b, long long sb,
-                                                                const AssessParams &P, int bx0, int by0, int ch,
-                                                                int rows_needed, unsigned (*XY)[AM_GP],
-                                                                unsigned (*QQ)[AM_GP], unsigned (*PP)[AM_GP])
+__device__ __forceinline__ unsigned assess_load_chunk(const unsigned char *__restrict__ a, long long sa,
+                                                      const unsigned char *__restrict__ b, long long sb,
+                                                      const AssessParams &P, int bx0, int by0, int ch,
+                                                      int rows_needed, unsigned (*XY)[AM_GP],
+                                                      unsigned (*QQ)[AM_GP], unsigned (*PP)[AM_GP])
 {
-    unsigned long long sse = 0;
+    // a thread squares at most 12 chunks x 3 groups x 4 pixels x 3 channels = 432 differences per block (< 2.9e7): 32 bits
+    unsigned sse = 0;
     const bool want_sse = (P.flags & ASSESS_SSE) != 0;
     if (RESIZE) {
         // one resized pixel per step, both images, kept as a rolled loop: the sampling (4 rows x 4 taps x CN, 64-bit
@@ -1833,9 +1835,11 @@ __global__ __launch_bounds__(AM_TX, 3) void k_assess_march(const unsigned char *
                                                       const unsigned char *__restrict__ b, long long sb,
                                                       AssessParams P, double *__restrict__ part)
 {
-    __shared__ __attribute__((aligned(16))) unsigned XY[AM_CH][AM_GP];   // x | y << 14
-    __shared__ __attribute__((aligned(16))) unsigned QQ[AM_CH][AM_GP];   // x * y
-    __shared__ __attribute__((aligned(16))) unsigned PP[AM_CH][AM_GP];   // x^2 + y^2
+    // one array, so the march addresses all three maps off ONE per-thread base register
+    __shared__ __attribute__((aligned(16))) unsigned L3[3][AM_CH][AM_GP];
+    unsigned (*XY)[AM_GP] = L3[0];                                       // x | y << 14
+    unsigned (*QQ)[AM_GP] = L3[1];                                       // x * y
+    unsigned (*PP)[AM_GP] = L3[2];                                       // x^2 + y^2
     // per-row 7-tap sums of the last seven rows, two dwords per column: {sx:14 | sy:11 @14 | sq lo:7 @25}, {sp:20 | sq hi:12 @20}
     __shared__ unsigned U[UNIF ? 7 : 1][2][AM_TX];
     __shared__ double red[AM_TX / 64][4];
@@ -1852,11 +1856,15 @@ __global__ __launch_bounds__(AM_TX, 3) void k_assess_march(const unsigned char *
     }
     unsigned t_xy = 0, t_p = 0, t_q = 0;                                // 49-sample window sums (uniform-7)
     double sum_int = 0.0, sum_all = 0.0, sum_u = 0.0;
-    unsigned long long sse = 0;
+    unsigned sse = 0;                                                   // this thread's squared differences (fits: see the loader)
     int slot = 0;                                                       // row index mod 7
     const double k0 = P.k[0], k1 = P.k[1], k2 = P.k[2], k3 = P.k[3], k4 = P.k[4], k5 = P.k[5];
-    lds_cu32 *xy0 = (lds_cu32 *)&XY[0][c], *q0 = (lds_cu32 *)&QQ[0][c], *p0 = (lds_cu32 *)&PP[0][c];
-    double sum_edge = 0.0;                                              // full-frame samples of the 5 top / bottom image rows
+    lds_cu32 *xy0 = (lds_cu32 *)&L3[0][0][c];
+    constexpr int MAPB = AM_CH * AM_GP * 4;                             // bytes between the maps
+    // full-frame samples of the 5 top / bottom image rows: touched only by the first and last block rows, so the running
+    // sum lives in LDS (2 KB) instead of two registers of every thread of every block
+    __shared__ double EDGE[(GAUSS && SAMEC) ? AM_TX : 1];
+    if (GAUSS && SAMEC) EDGE[c] = 0.0;                                  // own slot only: no barrier needed
 #pragma unroll 1
     for (int ch = 0; ch < P.nch; ++ch) {
         if (ch * AM_CH >= rows_needed) break;
@@ -1867,7 +1875,8 @@ __global__ __launch_bounds__(AM_TX, 3) void k_assess_march(const unsigned char *
         for (int s = 0; s < AM_CH; ++s) {
             const int r = ch * AM_CH + s;
             if (r >= rows_needed) continue;                             // block-uniform (no break: the loop must unroll)
-            lds_cu32 *rxy = lds_row_base(xy0, s * AM_GP * 4), *rq = lds_row_base(q0, s * AM_GP * 4), *rp = lds_row_base(p0, s * AM_GP * 4);
+            lds_cu32 *rxy = lds_row_base(xy0, s * AM_GP * 4), *rq = lds_row_base(xy0, MAPB + s * AM_GP * 4),
+                     *rp = lds_row_base(xy0, 2 * MAPB + s * AM_GP * 4);
             unsigned xy[11], qv[11], pv[11];
 #pragma unroll
             for (int j = 0; j < 11; ++j) {
@@ -1946,7 +1955,7 @@ __global__ __launch_bounds__(AM_TX, 3) void k_assess_march(const unsigned char *
                         // ten) image rows outside the crop, which only the blocks at the top / bottom ever see
                         const double sv = ssim_quot(u[0], u[1], u[2], u[3], P.c1a, P.c2a);
                         sum_all += sv;
-                        if (!inner_row) sum_edge += sv;
+                        if (!inner_row) EDGE[c] += sv;
                     } else {
                         if (P.flags & ASSESS_SIMPLE) sum_all += ssim_quot(u[0], u[1], u[2], u[3], P.c1b, P.c2b);
                         if (inner_row && (P.flags & ASSESS_GAUSS)) sum_int += ssim_quot(u[0], u[1], u[2], u[3], P.c1a, P.c2a);
@@ -1956,7 +1965,7 @@ __global__ __launch_bounds__(AM_TX, 3) void k_assess_march(const unsigned char *
         }
     }
     // column validity, once: the full-frame variant counts every image column, the cropped ones lose 5 / 3 per side
-    if (GAUSS && SAMEC) sum_int = sum_all - sum_edge;
+    if (GAUSS && SAMEC) sum_int = sum_all - EDGE[c];
     if (!(mx < P.w)) sum_all = 0.0;
     if (!(mx >= AM_R && mx < P.w - AM_R)) sum_int = 0.0;
     if (!(mx >= 3 && mx < P.w - 3)) sum_u = 0.0;
