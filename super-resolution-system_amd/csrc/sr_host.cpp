@@ -304,6 +304,54 @@ int sr_exchange_plan(const sr_tile_rect *h_tiles, int n, int cn, int levels, int
     return SR_OK;
 }
 
+// The batch of one rank's exchange as plain (peer, pointer, bytes) lists: what sr_comm_exchange_tile_rows posts to RCCL,
+// for hosts that move the rows themselves (host only; nothing is dereferenced).
+int sr_exchange_xfers(const sr_tile_rect *h_tiles, int n, int cn, int world, int me, const int *h_need, const int *h_owner,
+                      const void *const *d_owned, const int64_t *owned_stride, void *const *d_recv, sr_xfer *sends, int cap_send,
+                      int *n_send, sr_xfer *recvs, int cap_recv, int *n_recv)
+{
+    if (!h_tiles || !h_need || !h_owner || !d_owned || !owned_stride || !d_recv || !n_send || !n_recv || n < 1 || cn < 1 || world < 1 ||
+        me < 0 || me >= world || cap_send < 0 || cap_recv < 0 || (cap_send && !sends) || (cap_recv && !recvs))
+        return sr_set_error(SR_ERR_INVALID_ARG, "sr_exchange_xfers: bad arguments");
+    for (int t = 0; t < n; ++t)
+        if (h_owner[t] < 0 || h_owner[t] >= world)
+            return sr_set_error(SR_ERR_INVALID_ARG, "sr_exchange_xfers: tile %d owner %d of %d ranks", t, h_owner[t], world);
+    int ns = 0, nr = 0;
+    for (int r = 0; r < world; ++r) {                           // sends: reader-major, then tile
+        if (r == me) continue;
+        for (int t = 0; t < n; ++t) {
+            const int a = h_need[((size_t)r * n + t) * 2], b = h_need[((size_t)r * n + t) * 2 + 1];
+            if (a >= b || h_owner[t] != me) continue;
+            const int64_t row = (int64_t)h_tiles[t].w * cn;     // u8 tiles (the SR output)
+            if (!d_owned[t] || a < 0 || b > h_tiles[t].h)
+                return sr_set_error(SR_ERR_INVALID_ARG, "sr_exchange_xfers: owned tile %d: pointer %p, rows [%d, %d) of %d", t, d_owned[t], a,
+                                    b, h_tiles[t].h);
+            if (owned_stride[t] != row)                         // the receiver posts ONE dense transfer per tile
+                return sr_set_error(SR_ERR_UNSUPPORTED, "sr_exchange_xfers: tile %d is sent to rank %d and must be dense (stride %lld != "
+                                    "%d * %d)", t, r, (long long)owned_stride[t], h_tiles[t].w, cn);
+            if (ns < cap_send) sends[ns] = {r, (void *)((const char *)d_owned[t] + (int64_t)a * row), (uint64_t)((int64_t)(b - a) * row)};
+            ++ns;
+        }
+    }
+    for (int o = 0; o < world; ++o) {                           // receives: owner-major, then tile
+        if (o == me) continue;
+        for (int t = 0; t < n; ++t) {
+            const int a = h_need[((size_t)me * n + t) * 2], b = h_need[((size_t)me * n + t) * 2 + 1];
+            if (a >= b || h_owner[t] != o) continue;
+            if (!d_recv[t])
+                return sr_set_error(SR_ERR_INVALID_ARG, "sr_exchange_xfers: no receive buffer for rows [%d, %d) of tile %d", a, b, t);
+            if (nr < cap_recv) recvs[nr] = {o, d_recv[t], (uint64_t)((int64_t)(b - a) * h_tiles[t].w * cn)};
+            ++nr;
+        }
+    }
+    *n_send = ns;
+    *n_recv = nr;
+    if (ns > cap_send || nr > cap_recv)
+        return sr_set_error(SR_ERR_SHAPE, "sr_exchange_xfers: %d sends / %d receives, room for %d / %d", ns, nr, cap_send, cap_recv);
+    return SR_OK;
+}
+
+
 double sr_psnr_from_sse(uint64_t sse, uint64_t count, double data_range)
 {
     if (count == 0) return NAN;
