@@ -1,0 +1,140 @@
+/* A non-Python host of the path, in plain C, using nothing but include/sr_hip.h: tile -> [plan -> RCCL exchange] ->
+ * Laplacian blend of this rank's strip -> PSNR / SSIM partial sums -> all-reduce.  One process per GPU; ranks meet through
+ * a file that carries the RCCL unique id (any transport will do: MPI_Bcast, a socket).
+ *
+ *   gcc -std=c99 -O2 -I include examples/strip_host.c -L super-resolution-system_amd -lsrhip \
+ *       -Wl,-rpath,$PWD/super-resolution-system_amd -o strip_host
+ *   ./strip_host                         one GPU (the communicator has one rank; nothing is exchanged)
+ *   ./strip_host 2 0 /tmp/id & ./strip_host 2 1 /tmp/id        two GPUs of one node (rank r uses device r)
+ *
+ * The geometry is the reference's own demo (blending_module.py:1774-1814): 2 x 2 tiles of 512 x 512, overlap 100 -> a
+ * 924 x 924 canvas, 6 levels, cosine weights.  Prints the four metric sums of the whole canvas and an FNV-1a hash of the
+ * rows this rank blended; tests/test_gpu_comm.py checks both against the Python host. */
+#define _POSIX_C_SOURCE 200809L
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "sr_hip.h"
+
+#define OK(call)                                                                          \
+    do {                                                                                  \
+        int rc_ = (call);                                                                 \
+        if (rc_ != SR_OK) { fprintf(stderr, "%s -> %d: %s\n", #call, rc_, sr_last_error()); return 1; } \
+    } while (0)
+
+enum { TILE = 512, OV = 100, GRID = 2, CN = 3, LEVELS = 6, HALO = 5, N = GRID * GRID, SIDE = GRID * (TILE - OV) + OV };
+
+static uint32_t lcg(uint32_t *s) { *s = *s * 1664525u + 1013904223u; return *s >> 24; }
+
+int main(int argc, char **argv)
+{
+    const int world = argc > 2 ? atoi(argv[1]) : 1, rank = argc > 2 ? atoi(argv[2]) : 0;
+    const char *id_path = argc > 3 ? argv[3] : NULL;
+    const int H = SIDE, W = SIDE;
+    const int64_t stride = (int64_t)W * CN;
+
+    /* the "SR output" every rank can produce (a smooth field plus noise) and the image it is assessed against */
+    uint8_t *img = (uint8_t *)malloc((size_t)H * stride), *ref = (uint8_t *)malloc((size_t)H * stride);
+    uint32_t s1 = 20260313u, s2 = 42u;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W * CN; ++x) {
+            const int base = 96 + ((x / CN) * 5 + y * 3) % 64;
+            img[(size_t)y * stride + x] = (uint8_t)(base + (int)(lcg(&s1) % 25));
+            ref[(size_t)y * stride + x] = (uint8_t)(base + (int)(lcg(&s2) % 25));
+        }
+
+    sr_ctx *ctx;
+    OK(sr_ctx_create(rank, &ctx));
+    void *d_img, *d_ref, *d_canvas, *d_sums;
+    OK(sr_dev_alloc(ctx, (size_t)H * stride, &d_img));
+    OK(sr_dev_alloc(ctx, (size_t)H * stride, &d_ref));
+    OK(sr_dev_alloc(ctx, (size_t)H * stride, &d_canvas));
+    OK(sr_dev_alloc(ctx, sizeof(sr_assess_sums), &d_sums));
+    OK(sr_memcpy_h2d(ctx, d_img, img, (size_t)H * stride));
+    OK(sr_memcpy_h2d(ctx, d_ref, ref, (size_t)H * stride));
+    OK(sr_memset_d(ctx, d_canvas, 0, (size_t)H * stride));
+
+    /* geometry and plan: identical on every rank */
+    sr_tile_rect rects[N];
+    int xywh[N * 4];
+    for (int t = 0; t < N; ++t) {
+        rects[t].x = (t % GRID) * (TILE - OV); rects[t].y = (t / GRID) * (TILE - OV); rects[t].w = TILE; rects[t].h = TILE;
+        xywh[4 * t] = rects[t].x; xywh[4 * t + 1] = rects[t].y; xywh[4 * t + 2] = TILE; xywh[4 * t + 3] = TILE;
+    }
+    int *bounds = (int *)malloc(sizeof(int) * (size_t)(world + 1)), *rows = (int *)malloc(sizeof(int) * 2 * (size_t)world);
+    int *need = (int *)malloc(sizeof(int) * 2 * (size_t)world * N), owner[N];
+    OK(sr_exchange_plan(rects, N, CN, LEVELS, H, W, world, HALO, SR_OWNER_BALANCED, bounds, rows, need, owner));
+
+    /* tile stage: a rank cuts only the tiles it owns */
+    void *d_tile[N] = {0}, *d_recv[N] = {0}, *d_blend[N] = {0};
+    const void *d_owned[N] = {0};
+    int64_t strides[N];
+    int own_xywh[N * 4], n_own = 0;
+    void *own_ptr[N];
+    int64_t own_stride[N];
+    for (int t = 0; t < N; ++t) {
+        strides[t] = (int64_t)TILE * CN;
+        const int r0 = need[(rank * N + t) * 2], r1 = need[(rank * N + t) * 2 + 1];
+        if (owner[t] == rank) {
+            OK(sr_dev_alloc(ctx, (size_t)TILE * TILE * CN, &d_tile[t]));
+            memcpy(&own_xywh[4 * n_own], &xywh[4 * t], 4 * sizeof(int));
+            own_ptr[n_own] = d_tile[t]; own_stride[n_own] = strides[t]; ++n_own;
+            d_owned[t] = d_tile[t]; d_blend[t] = d_tile[t];
+        } else if (r0 < r1) {                       /* rows this strip needs of a tile another rank owns */
+            OK(sr_dev_alloc(ctx, (size_t)(r1 - r0) * TILE * CN, &d_recv[t]));
+            d_blend[t] = (char *)d_recv[t] - (int64_t)r0 * strides[t];          /* virtual row 0 */
+        }
+    }
+    if (n_own) OK(sr_tile_extract(ctx, (const uint8_t *)d_img, H, W, CN, stride, own_xywh, n_own, own_ptr, own_stride));
+
+    /* communicator + exchange */
+    uint8_t id[SR_COMM_ID_BYTES];
+    if (world == 1) {
+        OK(sr_comm_unique_id(id));
+    } else {
+        if (!id_path) { fprintf(stderr, "usage: strip_host WORLD RANK ID_FILE\n"); return 2; }
+        if (rank == 0) {
+            OK(sr_comm_unique_id(id));
+            char tmp[512];
+            snprintf(tmp, sizeof tmp, "%s.tmp", id_path);
+            FILE *f = fopen(tmp, "wb");
+            if (!f || fwrite(id, 1, sizeof id, f) != sizeof id || fclose(f) != 0 || rename(tmp, id_path) != 0) return 3;
+        } else {
+            FILE *f = NULL;
+            for (int tries = 0; tries < 600 && !(f = fopen(id_path, "rb")); ++tries) { struct timespec ts = {0, 100000000}; nanosleep(&ts, NULL); }
+            if (!f || fread(id, 1, sizeof id, f) != sizeof id) return 3;
+            fclose(f);
+        }
+    }
+    sr_comm *comm;
+    OK(sr_comm_init(ctx, id, world, rank, &comm));
+    OK(sr_comm_exchange_tile_rows(ctx, comm, rects, N, CN, need, owner, d_owned, strides, d_recv));
+
+    /* blend this rank's rows, assess its strip, reduce */
+    sr_blend_plan *plan;
+    OK(sr_blend_plan_create(ctx, rects, N, CN, H, W, LEVELS, SR_W_COSINE, rows[2 * rank], rows[2 * rank + 1], &plan));
+    OK(sr_laplacian_blend(plan, SR_U8, d_blend, strides, (uint8_t *)d_canvas, stride, NULL));
+    OK(sr_assess_u8_async(ctx, (const uint8_t *)d_ref, stride, (const uint8_t *)d_canvas, stride, H, W, CN, 15, 255.0, bounds[rank],
+                          bounds[rank + 1], SR_ASSESS_ALL, (sr_assess_sums *)d_sums));
+    OK(sr_comm_allreduce_f64(ctx, comm, (double *)d_sums, 4));
+    OK(sr_ctx_sync(ctx));
+
+    sr_assess_sums sums;
+    OK(sr_memcpy_d2h(ctx, &sums, d_sums, sizeof sums));
+    uint8_t *canvas = (uint8_t *)malloc((size_t)H * stride);
+    OK(sr_memcpy_d2h(ctx, canvas, d_canvas, (size_t)H * stride));
+    uint64_t hash = 1469598103934665603ull;
+    for (int64_t i = (int64_t)bounds[rank] * stride; i < (int64_t)bounds[rank + 1] * stride; ++i) hash = (hash ^ canvas[i]) * 1099511628211ull;
+    printf("{\"world\": %d, \"rank\": %d, \"rows\": [%d, %d], \"sse\": %.17g, \"ssim_uniform\": %.17g, \"ssim_gauss\": %.17g, "
+           "\"ssim_simple\": %.17g, \"strip_fnv1a\": \"%016llx\"}\n", world, rank, bounds[rank], bounds[rank + 1], sums.sse, sums.ssim_uniform,
+           sums.ssim_gauss, sums.ssim_simple, (unsigned long long)hash);
+
+    OK(sr_blend_plan_destroy(plan));
+    OK(sr_comm_destroy(comm));
+    OK(sr_ctx_destroy(ctx));
+    free(img); free(ref); free(canvas); free(bounds); free(rows); free(need);
+    return 0;
+}

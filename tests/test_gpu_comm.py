@@ -47,3 +47,70 @@ def test_comm_world1_self_exchange(ctx, rng):
                 t.free()
     finally:
         comm.close()
+
+
+def _lcg_bytes(seed, n):
+    """The C example's generator, vectorised: s_k = a^k s_0 + c (a^(k-1) + ... + 1) mod 2^32, value = s_k >> 24."""
+    a, c = np.uint32(1664525), np.uint32(1013904223)
+    with np.errstate(over="ignore"):
+        ak = np.cumprod(np.full(n, a, dtype=np.uint32), dtype=np.uint32)           # a^1 .. a^n (wraps mod 2^32)
+        geo = np.cumsum(np.concatenate([[np.uint32(1)], ak[:-1]]), dtype=np.uint32)   # 1 + a + ... + a^(k-1)
+        s = ak * np.uint32(seed) + c * geo
+    return (s >> np.uint32(24)).astype(np.int64)
+
+
+def test_c_host_example(ctx, tmp_path):
+    """examples/strip_host.c -- a plain C99 host that includes nothing but include/sr_hip.h -- is compiled with gcc, linked
+    against libsrhip.so and run on the GPU (one rank: plan, RCCL communicator, exchange, strip blend, assessment,
+    all-reduce); its metric sums and the hash of its canvas must equal what the Python host computes for the same
+    synthetic images."""
+    import json
+    import os
+    import shutil
+    import subprocess
+    import _native
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(_native.LIB_PATH)
+    exe = str(tmp_path / "strip_host")
+    subprocess.run(["gcc", "-std=c99", "-O2", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "examples", "strip_host.c"), "-L", libdir, "-lsrhip", "-Wl,-rpath," + libdir, "-o", exe],
+                   check=True, capture_output=True, text=True, timeout=300)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    # the same images, the same path through the Python host
+    tile, ov, grid, cn = 512, 100, 2, 3
+    side = grid * (tile - ov) + ov
+    xs = np.arange(side * cn) // cn
+    base = 96 + (xs[None, :] * 5 + np.arange(side)[:, None] * 3) % 64
+    img = (base + _lcg_bytes(20260313, side * side * cn).reshape(side, side * cn) % 25).astype(np.uint8)
+    ref = (base + _lcg_bytes(42, side * side * cn).reshape(side, side * cn) % 25).astype(np.uint8)
+    rects = [((t % grid) * (tile - ov), (t // grid) * (tile - ov), tile, tile) for t in range(grid * grid)]
+    d_img, d_ref = ctx.upload(img), ctx.upload(ref)
+    tiles = [ctx.alloc(tile * tile * cn) for _ in rects]
+    canvas = ctx.alloc(side * side * cn)
+    sums = ctx.alloc(32)
+    try:
+        ctx.memset(canvas.ptr, 0, side * side * cn)
+        ctx.tile_extract(d_img.ptr, side, side, cn, side * cn, rects, [t.ptr for t in tiles], [tile * cn] * len(rects))
+        plan = _native.BlendPlan(ctx, rects, cn, side, side, 6, "cosine")
+        plan.blend([t.ptr for t in tiles], [tile * cn] * len(rects), canvas.ptr, side * cn)
+        ctx.assess_u8_async(d_ref.ptr, side * cn, canvas.ptr, side * cn, side, side, cn, sums.ptr)
+        ctx.sync()
+        want = ctx.download(sums.ptr, (4,), np.float64)
+        out = ctx.download(canvas.ptr, (side * side * cn,), np.uint8)
+        plan.close()
+    finally:
+        for b in [d_img, d_ref, canvas, sums] + tiles:
+            b.free()
+    assert got["rows"] == [0, side] and got["world"] == 1
+    assert [got["sse"], got["ssim_uniform"], got["ssim_gauss"], got["ssim_simple"]] == want.tolist()
+    h = 1469598103934665603
+    for v in out.tolist():
+        h = ((h ^ v) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert got["strip_fnv1a"] == f"{h:016x}"
+    assert want[0] > 0 and 0.0 < want[2] / (side * side) < 1.0
