@@ -51,6 +51,8 @@ struct sr_ctx {
     CachedTable extract_tab;                            // tile-extract descriptors
     CachedTable resize_tab;                             // cubic tables of the resized assessment
     CachedTable cubic_tab;                              // cubic tables of sr_resize_cubic_u8
+    void *gray_planes = nullptr;                        // resized gray planes + SSE partials of the resized assessment
+    size_t gray_planes_bytes = 0;
 };
 
 // Enqueue a small host->device table upload whose source stays alive until the next sync.

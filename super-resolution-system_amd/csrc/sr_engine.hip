@@ -1569,10 +1569,6 @@ enum { ASSESS_SSE = 1, ASSESS_UNIFORM = 2, ASSESS_GAUSS = 4, ASSESS_SIMPLE = 8, 
 struct AssessParams {
     int h, w, shift, ry0, ry1, flags, same_c;
     int nch, ty;       // chunks of 11 rows a block marches, and the rows it produces (11 nch - 10)
-    // resized assessment (sr_assess_resized_u8): h, w above are the RESIZED size the metrics are taken on; the images
-    // behind a / b are sh x sw and every pixel is the cv2.INTER_CUBIC sample through these tables (else null)
-    int sh, sw;
-    const CubicTab *xt, *yt;
     double c1a, c2a;   // constants for data_range (uniform / gauss)
     double c1b, c2b;   // constants for 255 (simple)
     double k1u, k2u;   // 49^2 c1a and 48*49 c2a: the uniform-7 variant in integer-scaled form
@@ -1687,7 +1683,7 @@ __device__ __forceinline__ void cubic_sample(const unsigned char *__restrict__ s
 
 // gray conversion + per-pixel products of 4-pixel groups of chunk `ch` into LDS; returns this thread's share of the
 // squared differences of the block's own pixels
-template <int CN, bool RESIZE>
+template <int CN>
 __device__ __forceinline__ unsigned assess_load_chunk(const unsigned char *__restrict__ a, long long sa,
                                                       const unsigned char *__restrict__ b, long long sb,
                                                       const AssessParams &P, int bx0, int by0, int ch,
@@ -1697,38 +1693,6 @@ __device__ __forceinline__ unsigned assess_load_chunk(const unsigned char *__res
     // a thread squares at most 12 chunks x 3 groups x 4 pixels x 3 channels = 432 differences per block (< 2.9e7): 32 bits
     unsigned sse = 0;
     const bool want_sse = (P.flags & ASSESS_SSE) != 0;
-    if (RESIZE) {
-        // one resized pixel per step, both images, kept as a rolled loop: the sampling (4 rows x 4 taps x CN, 64-bit
-        // accumulators) is register-hungry and the march that follows needs its 150 VGPRs for three waves per SIMD
-#pragma unroll 1
-        for (int i = threadIdx.x; i < AM_CH * AM_GP; i += AM_TX) {
-            const int ly = i / AM_GP, lx = i - ly * AM_GP;
-            const int lr = ch * AM_CH + ly;
-            if (lr >= rows_needed) break;
-            const int gy = by0 - AM_R + lr, gx = bx0 - AM_R + lx;
-            const CubicTab Y = P.yt[reflect101(gy, P.h)], X = P.xt[reflect101(gx, P.w)];
-            int va[CN], vb[CN];
-            cubic_sample<CN>(a, sa, P.sh, P.sw, X, Y, va);
-            cubic_sample<CN>(b, sb, P.sh, P.sw, X, Y, vb);
-            int ga, gb;
-            if (CN == 3) {
-                ga = gray_rgb(va[0], va[1], va[2], P.shift);
-                gb = gray_rgb(vb[0], vb[1], vb[2], P.shift);
-            } else {
-                ga = va[0];
-                gb = vb[0];
-            }
-            XY[ly][lx] = (unsigned)ga | ((unsigned)gb << 14);
-            QQ[ly][lx] = (unsigned)__mul24(ga, gb);
-            PP[ly][lx] = (unsigned)(__mul24(ga, ga) + __mul24(gb, gb));
-            if (want_sse && lr >= AM_R && lr < AM_R + P.ty && gy < P.ry1 && gy < P.h && lx >= AM_R && lx < AM_R + AM_TX &&
-                gx < P.w) {
-#pragma unroll
-                for (int c = 0; c < CN; ++c) sse += (unsigned)((va[c] - vb[c]) * (va[c] - vb[c]));
-            }
-        }
-        return sse;
-    }
     for (int i = threadIdx.x; i < AM_CH * (AM_GP / 4); i += AM_TX) {
         const int ly = i / (AM_GP / 4), lx = (i - ly * (AM_GP / 4)) * 4;
         const int lr = ch * AM_CH + ly;
@@ -1830,7 +1794,7 @@ __device__ __forceinline__ double ssim_quot(double ux, double uy, double spq, do
 // (out-of-image columns hold reflected data, so their values are finite and simply dropped).
 // In LDS x and y travel packed as x | y << 14: pair sums (<= 510), 7-tap sums (<= 1785) and 49-sample window sums
 // (<= 12495 < 2^14) all stay inside their fields, so one integer add serves both images at every stage.
-template <int CN, bool RESIZE, bool GAUSS, bool UNIF, bool SAMEC>
+template <int CN, bool GAUSS, bool UNIF, bool SAMEC>
 __global__ __launch_bounds__(AM_TX, 3) void k_assess_march(const unsigned char *__restrict__ a, long long sa,
                                                       const unsigned char *__restrict__ b, long long sb,
                                                       AssessParams P, double *__restrict__ part)
@@ -1869,7 +1833,7 @@ __global__ __launch_bounds__(AM_TX, 3) void k_assess_march(const unsigned char *
     for (int ch = 0; ch < P.nch; ++ch) {
         if (ch * AM_CH >= rows_needed) break;
         __syncthreads();                                                // the previous chunk has been read
-        sse += assess_load_chunk<CN, RESIZE>(a, sa, b, sb, P, bx0, by0, ch, rows_needed, XY, QQ, PP);
+        sse += assess_load_chunk<CN>(a, sa, b, sb, P, bx0, by0, ch, rows_needed, XY, QQ, PP);
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < AM_CH; ++s) {
@@ -2389,6 +2353,7 @@ int sr_ctx_destroy(sr_ctx *ctx)
         }
         for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
         if (ctx->scratch) (void)hipFree(ctx->scratch);
+        if (ctx->gray_planes) (void)hipFree(ctx->gray_planes);
         if (ctx->extract_tab.d) (void)hipFree(ctx->extract_tab.d);
         if (ctx->resize_tab.d) (void)hipFree(ctx->resize_tab.d);
         if (ctx->cubic_tab.d) (void)hipFree(ctx->cubic_tab.d);
@@ -3487,6 +3452,51 @@ int sr_sse_u8(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uint8_t *
 // ---- fused assessment ---------------------------------------------------------------------------------------
 }  // extern "C"
 
+// Stage 1 of the resized assessment: one thread = 4 consecutive pixels of the RESIZED images; cv2.resize(INTER_CUBIC) sample of
+// both images (cubic_sample: the arithmetic of k_resize_cubic), gray of each, the squared channel differences.  Writes the
+// two gray planes and one SSE partial per block (exact: integers, < 2^53).
+template <int CN>
+__global__ __launch_bounds__(256) void k_resize_gray_pair(const unsigned char *__restrict__ a, long long sa,
+                                                          const unsigned char *__restrict__ b, long long sb, int sh, int sw,
+                                                          const CubicTab *__restrict__ xt, const CubicTab *__restrict__ yt, int dh,
+                                                          int dw, int shift, unsigned char *__restrict__ ga,
+                                                          unsigned char *__restrict__ gb, long long pitch, double *__restrict__ part)
+{
+    __shared__ double ws[4];
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y;
+    unsigned sse = 0, pa = 0, pb = 0;
+    if (y < dh && x0 < dw) {
+        const CubicTab Y = yt[y];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int x = min(x0 + k, dw - 1);              // columns past the end repeat the last one and are not counted
+            int va[CN], vb[CN];
+            cubic_sample<CN>(a, sa, sh, sw, xt[x], Y, va);
+            cubic_sample<CN>(b, sb, sh, sw, xt[x], Y, vb);
+            const int g0 = CN == 3 ? gray_rgb(va[0], va[1], va[2], shift) : va[0];
+            const int g1 = CN == 3 ? gray_rgb(vb[0], vb[1], vb[2], shift) : vb[0];
+            pa |= (unsigned)g0 << (8 * k);
+            pb |= (unsigned)g1 << (8 * k);
+            if (x0 + k < dw) {
+#pragma unroll
+                for (int c = 0; c < CN; ++c) sse += (unsigned)((va[c] - vb[c]) * (va[c] - vb[c]));
+            }
+        }
+        *(unsigned *)(ga + (size_t)y * pitch + x0) = pa;    // pitch is a multiple of 64: the row padding takes the tail
+        *(unsigned *)(gb + (size_t)y * pitch + x0) = pb;
+    }
+    const double s = wave_sum_f64((double)sse);
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    if ((tid & 63) == 0) ws[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
+__global__ void k_store_sse(const double *__restrict__ src, sr_assess_sums *__restrict__ out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) out->sse = src[0];
+}
+
 // Final reduction of the assessment: ONE block sums the per-block partials part[i * 4 + comp] (fixed order: a
 // strided serial sum per thread, then a fixed tree -- deterministic) and writes the four sums.
 __global__ __launch_bounds__(256) void k_assess_finish(const double *__restrict__ part, long long n, int flags,
@@ -3567,17 +3577,15 @@ int sr_ssim_count(int h, int w, int mode, int row_begin, int row_end, uint64_t *
     return SR_OK;
 }
 
-// Shared body of sr_assess_u8_async / sr_assess_resized_u8_async.  (h, w): the image the metrics are taken on; with
-// src_h > 0 the buffers are src_h x src_w and that image is their cv2.INTER_CUBIC resize, sampled on the fly.
+// Shared body of sr_assess_u8_async / sr_assess_resized_u8_async (which hands it the resized gray planes).
 static int assess_impl(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uint8_t *d_b, int64_t stride_b, int h,
                        int w, int cn, int gray_shift, double data_range, int row_begin, int row_end, int flags,
-                       sr_assess_sums *d_out, int src_h, int src_w, const char *scope)
+                       sr_assess_sums *d_out, const char *scope)
 {
-    const bool resized = src_h > 0;
     if (!d_a || !d_b || !d_out) return sr_set_error(SR_ERR_INVALID_ARG, "%s: null argument", scope);
     if (h < 1 || w < 1 || (cn != 1 && cn != 3)) return sr_set_error(SR_ERR_INVALID_ARG, "%s: need h,w >= 1 and 1 or 3 channels", scope);
     if (gray_shift != 14 && gray_shift != 15) return sr_set_error(SR_ERR_INVALID_ARG, "%s: gray_shift must be 14 or 15", scope);
-    const int64_t min_stride = (int64_t)(resized ? src_w : w) * cn;
+    const int64_t min_stride = (int64_t)w * cn;
     if (stride_a < min_stride || stride_b < min_stride) return sr_set_error(SR_ERR_SHAPE, "%s: stride smaller than a row", scope);
     row_begin = std::max(row_begin, 0);
     row_end = std::min(row_end, h);
@@ -3594,17 +3602,6 @@ static int assess_impl(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const 
     gauss_taps(P.k);
     const int rows = row_end - row_begin;
     if (rows > 0 && (flags & ASSESS_ALL_BITS)) {
-        if (resized) {
-            // both axes' tables in one cached device table (re-used while the geometry stays the same)
-            std::vector<CubicTab> xt, yt;
-            cubic_table(src_w, w, xt);
-            cubic_table(src_h, h, yt);
-            xt.insert(xt.end(), yt.begin(), yt.end());
-            HIPCHK(upload_cached(ctx, ctx->resize_tab, xt.data(), sizeof(CubicTab) * xt.size()));
-            P.sh = src_h; P.sw = src_w;
-            P.xt = (const CubicTab *)ctx->resize_tab.d;
-            P.yt = P.xt + w;
-        }
         // Blocks are equal work, 3 resident per CU: pick the chunk count that minimises (rounds of blocks) x (rows a
         // block marches) -- long blocks amortise the 10-row halo, short ones avoid a mostly empty last round on strips.
         const long long gbx = (w + AM_TX - 1) / AM_TX;
@@ -3629,19 +3626,19 @@ static int assess_impl(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const 
         {
             ProfScope ps(ctx, scope);
             const dim3 grid((unsigned)gbx, (unsigned)gby), block(AM_TX);
-#define LAUNCH_ASSESS(CNV, RS, GS, US, SC)                                                                           \
-    hipLaunchKernelGGL((k_assess_march<CNV, RS, GS, US, SC>), grid, block, 0, ctx->stream, d_a, (long long)stride_a, d_b, \
+#define LAUNCH_ASSESS(CNV, GS, US, SC)                                                                               \
+    hipLaunchKernelGGL((k_assess_march<CNV, GS, US, SC>), grid, block, 0, ctx->stream, d_a, (long long)stride_a, d_b,   \
                        (long long)stride_b, P, part)
-#define LAUNCH_ASSESS_V(CNV, RS)                                                                                        \
+#define LAUNCH_ASSESS_V(CNV)                                                                                            \
     do {                                                                                                                \
-        if (gauss && unif) { if (P.same_c) LAUNCH_ASSESS(CNV, RS, true, true, true); else LAUNCH_ASSESS(CNV, RS, true, true, false); } \
-        else if (gauss) { if (P.same_c) LAUNCH_ASSESS(CNV, RS, true, false, true); else LAUNCH_ASSESS(CNV, RS, true, false, false); } \
-        else if (unif) LAUNCH_ASSESS(CNV, RS, false, true, true);                                                       \
-        else LAUNCH_ASSESS(CNV, RS, false, false, true);                                                                \
+        if (gauss && unif) { if (P.same_c) LAUNCH_ASSESS(CNV, true, true, true); else LAUNCH_ASSESS(CNV, true, true, false); } \
+        else if (gauss) { if (P.same_c) LAUNCH_ASSESS(CNV, true, false, true); else LAUNCH_ASSESS(CNV, true, false, false); } \
+        else if (unif) LAUNCH_ASSESS(CNV, false, true, true);                                                           \
+        else LAUNCH_ASSESS(CNV, false, false, true);                                                                    \
     } while (0)
             const bool gauss = (flags & (ASSESS_GAUSS | ASSESS_SIMPLE)) != 0, unif = (flags & ASSESS_UNIFORM) != 0;
-            if (cn == 3) { if (resized) LAUNCH_ASSESS_V(3, true); else LAUNCH_ASSESS_V(3, false); }
-            else         { if (resized) LAUNCH_ASSESS_V(1, true); else LAUNCH_ASSESS_V(1, false); }
+            if (cn == 3) LAUNCH_ASSESS_V(3);
+            else LAUNCH_ASSESS_V(1);
 #undef LAUNCH_ASSESS_V
 #undef LAUNCH_ASSESS
             hipLaunchKernelGGL(k_assess_finish, dim3(1), dim3(256), 0, ctx->stream, part, (long long)nblk, flags, d_out);
@@ -3658,7 +3655,7 @@ int sr_assess_u8_async(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const 
 {
     CTX_ENTER(ctx);
     return assess_impl(ctx, d_a, stride_a, d_b, stride_b, h, w, cn, gray_shift, data_range, row_begin, row_end, flags,
-                       d_out, 0, 0, "assess_all");
+                       d_out, "assess_all");
 }
 
 int sr_assess_resized_u8_async(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uint8_t *d_b, int64_t stride_b,
@@ -3668,8 +3665,54 @@ int sr_assess_resized_u8_async(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a
     CTX_ENTER(ctx);
     if (h < 1 || w < 1 || dst_h < 1 || dst_w < 1)
         return sr_set_error(SR_ERR_INVALID_ARG, "sr_assess_resized_u8: need positive source and destination sizes");
-    return assess_impl(ctx, d_a, stride_a, d_b, stride_b, dst_h, dst_w, cn, gray_shift, data_range, 0, dst_h, flags, d_out,
-                       h, w, "assess_resized");
+    if (!d_a || !d_b || !d_out) return sr_set_error(SR_ERR_INVALID_ARG, "sr_assess_resized_u8: null argument");
+    if (cn != 1 && cn != 3) return sr_set_error(SR_ERR_INVALID_ARG, "sr_assess_resized_u8: need 1 or 3 channels");
+    if (gray_shift != 14 && gray_shift != 15) return sr_set_error(SR_ERR_INVALID_ARG, "sr_assess_resized_u8: gray_shift must be 14 or 15");
+    if (stride_a < (int64_t)w * cn || stride_b < (int64_t)w * cn) return sr_set_error(SR_ERR_SHAPE, "sr_assess_resized_u8: stride smaller than a row");
+    // Stage 1: every resized pixel of both images is sampled ONCE by a plain map kernel (8 independent 12-byte loads per
+    // pixel, full occupancy), its channel differences squared and summed, and only its two gray values kept: two u8 planes of
+    // the resized size (the RGB intermediates of cv2.resize are never materialised).  Stage 2: the ordinary one-channel
+    // assessment march over those planes.  (Sampling inside the march's loader -- round 1 -- kept the 88-register filter
+    // FIFO alive across a rolled, latency-bound loop: 1.98 ms for the three scales of a 200 MP pair.)
+    std::vector<CubicTab> xt, yt;
+    cubic_table(w, dst_w, xt);
+    cubic_table(h, dst_h, yt);
+    xt.insert(xt.end(), yt.begin(), yt.end());
+    HIPCHK(upload_cached(ctx, ctx->resize_tab, xt.data(), sizeof(CubicTab) * xt.size()));
+    const CubicTab *d_xt = (const CubicTab *)ctx->resize_tab.d, *d_yt = d_xt + dst_w;
+    const int64_t pitch = ((int64_t)dst_w + 63) / 64 * 64;
+    const dim3 block(64, 4), grid((unsigned)((dst_w + 255) / 256), (unsigned)((dst_h + 3) / 4));
+    const size_t nblk = (size_t)grid.x * grid.y, plane = (size_t)pitch * dst_h;
+    const size_t off_part = (2 * plane + 255) / 256 * 256, need = off_part + (nblk + 2 * (nblk / 1024 + 2)) * sizeof(double);
+    if (need > ctx->gray_planes_bytes) {
+        if (ctx->gray_planes) {
+            HIPCHK(stream_sync(ctx));
+            HIPCHK(hipFree(ctx->gray_planes));
+            ctx->gray_planes = nullptr;
+            ctx->gray_planes_bytes = 0;
+        }
+        HIPCHK(hipMalloc(&ctx->gray_planes, need));
+        ctx->gray_planes_bytes = need;
+    }
+    uint8_t *ga = (uint8_t *)ctx->gray_planes, *gb = ga + plane;
+    double *part = (double *)((char *)ctx->gray_planes + off_part), *buf0 = part + nblk, *buf1 = buf0 + nblk / 1024 + 2;
+    const bool want_sse = (flags & ASSESS_SSE) != 0;
+    const double *sse_ptr = nullptr;
+    {
+        ProfScope ps(ctx, "resize_gray");
+        if (cn == 3) hipLaunchKernelGGL(k_resize_gray_pair<3>, grid, block, 0, ctx->stream, d_a, (long long)stride_a, d_b, (long long)stride_b, h, w, d_xt, d_yt, dst_h, dst_w, gray_shift, ga, gb, (long long)pitch, part);
+        else hipLaunchKernelGGL(k_resize_gray_pair<1>, grid, block, 0, ctx->stream, d_a, (long long)stride_a, d_b, (long long)stride_b, h, w, d_xt, d_yt, dst_h, dst_w, gray_shift, ga, gb, (long long)pitch, part);
+        if (want_sse) sse_ptr = reduce_partials(ctx, part, (long long)nblk, 1, buf0, buf1);
+    }
+    int rc = check_launch("resize_gray");
+    if (rc) return rc;
+    rc = assess_impl(ctx, ga, pitch, gb, pitch, dst_h, dst_w, 1, gray_shift, data_range, 0, dst_h, flags & ~ASSESS_SSE, d_out, "assess_resized");
+    if (rc) return rc;
+    if (want_sse) {
+        hipLaunchKernelGGL(k_store_sse, dim3(1), dim3(64), 0, ctx->stream, sse_ptr, d_out);
+        return check_launch("assess_resized sse");
+    }
+    return SR_OK;
 }
 
 int sr_assess_resized_u8(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uint8_t *d_b, int64_t stride_b, int h,
