@@ -191,6 +191,32 @@ def run(cases: int = 200, seed: int = 1) -> int:
             bad += 1
             print("ASSESS MISMATCH", it, shape)
         da.free(); db.free()
+    # resized assessment (the downsample comparison of evaluate_full_reference): sample both images with INTER_CUBIC, then
+    # PSNR-SSE + SSIM on the resized pair -- against resize-then-assess through the oracle
+    rs = 0
+    for it in range(max(cases // 4, 10)):
+        h, w = int(rng.integers(12, 400)), int(rng.integers(12, 600))
+        dh, dw = max(7, int(h * rng.uniform(0.08, 1.3))), max(7, int(w * rng.uniform(0.08, 1.3)))
+        cn = int(rng.choice([1, 3]))
+        shape = (h, w, 3) if cn == 3 else (h, w)
+        a = rng.integers(0, 256, shape, dtype=np.uint8)
+        b = np.clip(a.astype(np.int16) + rng.integers(-25, 26, shape), 0, 255).astype(np.uint8)
+        da, db = ctx.upload(a), ctx.upload(b)
+        r = ctx.assess_resized_u8(da.ptr, w * cn, db.ptr, w * cn, h, w, cn, dh, dw, flags=_native.ASSESS_ALL)
+        ra, rb = oc.resize_cubic_u8(a, dw, dh), oc.resize_cubic_u8(b, dw, dh)
+        g0 = oc.rgb2gray_u8(ra) if cn == 3 else ra
+        g1 = oc.rgb2gray_u8(rb) if cn == 3 else rb
+        ok = r["sse"] == float(np.sum((ra.astype(np.int64) - rb.astype(np.int64)) ** 2))
+        for mode in ("uniform", "gauss", "simple"):
+            cnt = _native.ssim_count(dh, dw, mode)
+            if cnt:
+                ok = ok and abs(r[f"ssim_{mode}"] / cnt - oc.ssim(g0, g1, mode)) <= 1e-9
+        rs += 1
+        if not ok:
+            bad += 1
+            print("RESIZED ASSESS MISMATCH", it, shape, (dh, dw))
+        da.free(); db.free()
+    print(f"fuzz: {rs} resized assessments; ", end="")
     print(f"fuzz: {cases} blend cases ({compared} compared, {rejected} rejected by both, {strips} also as strips) + "
           f"{merges} feather merges + {worlds} strip worlds + {resizes} resizes + {max(cases // 4, 10)} assessment cases, {bad} mismatches")
     return bad
