@@ -447,7 +447,7 @@ int sr_encode_png(const uint8_t *h_img, int h, int w, int cn, int64_t stride, in
     const int rows_per_chunk = (int)std::max<size_t>(1, ((size_t)1 << 20) / frow);
     const size_t nchunks = ((size_t)h + rows_per_chunk - 1) / rows_per_chunk;
     std::vector<std::vector<uint8_t>> comp(nchunks);
-    std::vector<uLong> adler(nchunks);
+    std::vector<uLong> adler(nchunks), piece_crc(nchunks);
     std::vector<size_t> raw_len(nchunks);
     std::atomic<int> failed{0};
     parallel_for(nchunks, threads, [&](size_t c) {
@@ -536,6 +536,7 @@ int sr_encode_png(const uint8_t *h_img, int h, int w, int cn, int64_t stride, in
         if ((last && rc != Z_STREAM_END) || (!last && rc != Z_OK)) failed = 1;
         comp[c].resize(zs.total_out);
         deflateEnd(&zs);
+        piece_crc[c] = crc32(crc32(0L, (const Bytef *)"IDAT", 4), comp[c].data(), (uInt)comp[c].size());   // CRC of the piece's own IDAT chunk
     });
     if (failed) return sr_set_error(SR_ERR_INVALID_ARG, "sr_encode_png: deflate failed");
     uLong ad = adler32(0L, Z_NULL, 0);
@@ -547,21 +548,29 @@ int sr_encode_png(const uint8_t *h_img, int h, int w, int cn, int64_t stride, in
     ihdr[9] = cn == 1 ? 0 : (cn == 3 ? 2 : 6);
     ihdr[10] = ihdr[11] = ihdr[12] = 0;
     png_chunk(head, "IHDR", ihdr, 13);
-    // IDAT chunks: zlib header + the deflate pieces + Adler-32; a PNG chunk holds < 2^31 bytes, so cut at 1 GiB
-    std::vector<uint8_t> z;
-    size_t total = 2 + 4;
-    for (auto &c : comp) total += c.size();
-    z.reserve(total);
-    z.push_back(0x78);
-    z.push_back(level >= 7 ? 0xDA : (level >= 6 ? 0x9C : (level >= 2 ? 0x5E : 0x01)));
-    for (auto &c : comp) z.insert(z.end(), c.begin(), c.end());
-    be32(z, (uint32_t)ad);
-    std::vector<uint8_t> body;
-    body.reserve(z.size() + 64);
-    const size_t CH = (size_t)1 << 30;
-    for (size_t at = 0; at < z.size(); at += CH) png_chunk(body, "IDAT", z.data() + at, std::min(CH, z.size() - at));
-    png_chunk(body, "IEND", nullptr, 0);
-    if (!write_file(path, {&head, &body})) return sr_set_error(SR_ERR_INVALID_ARG, "sr_encode_png: cannot write %s", path);
+    // IDAT chunks (their boundaries are free: the zlib stream is the concatenation of all IDAT data): the 2-byte zlib header,
+    // then ONE chunk per deflate piece -- its CRC was taken by the thread that compressed it, and the piece is written from
+    // where it lies, so nothing of the compressed image is copied or re-read serially -- then the Adler-32.
+    std::vector<uint8_t> zhead, ztail;
+    const uint8_t zh[2] = {0x78, (uint8_t)(level >= 7 ? 0xDA : (level >= 6 ? 0x9C : (level >= 2 ? 0x5E : 0x01)))};
+    png_chunk(zhead, "IDAT", zh, 2);
+    const uint8_t adl[4] = {(uint8_t)(ad >> 24), (uint8_t)(ad >> 16), (uint8_t)(ad >> 8), (uint8_t)ad};
+    png_chunk(ztail, "IDAT", adl, 4);
+    png_chunk(ztail, "IEND", nullptr, 0);
+    std::vector<std::vector<uint8_t>> pre(nchunks), post(nchunks);
+    std::vector<const std::vector<uint8_t> *> parts = {&head, &zhead};
+    for (size_t c = 0; c < nchunks; ++c) {
+        if (comp[c].empty()) continue;
+        if (comp[c].size() >= ((size_t)1 << 31)) return sr_set_error(SR_ERR_UNSUPPORTED, "sr_encode_png: a deflate piece of 2 GiB");
+        be32(pre[c], (uint32_t)comp[c].size());
+        pre[c].insert(pre[c].end(), {'I', 'D', 'A', 'T'});
+        be32(post[c], (uint32_t)piece_crc[c]);
+        parts.push_back(&pre[c]);
+        parts.push_back(&comp[c]);
+        parts.push_back(&post[c]);
+    }
+    parts.push_back(&ztail);
+    if (!write_file(path, parts)) return sr_set_error(SR_ERR_INVALID_ARG, "sr_encode_png: cannot write %s", path);
     return SR_OK;
 }
 
