@@ -501,6 +501,30 @@ def test_detect_seams(rng):
         len(onp.detect_seams(result[:96, :120], [tiles[0]], [(0, 0)], 0.9, 16, 8))
 
 
+@pytest.mark.parametrize("cn", [3, 1])
+def test_seam_scan_cell_kernel_vs_oracle(rng, cn):
+    """The 16 / 8 geometry runs the cell kernel (2 x 2 cells of 8 x 8 per window), anything else the one-thread-per-window
+    kernel: both against the oracle on ragged tile sizes, canvas crops and several block rows / columns of cells."""
+    import blending_module as bm
+    shape = (3, 2)
+    th, tw = 217, 533                                         # 26 x 65 windows per tile: 4 x 3 blocks of 31 x 7
+    tiles = []
+    for i in range(shape[0] * shape[1]):
+        t = _img(rng, th, tw) if cn == 3 else _img(rng, th, tw)[..., 0]
+        tiles.append(np.clip(t.astype(np.int16) + 9 * i - 20, 0, 255).astype(np.uint8))
+    infos, _ = bm.create_tile_grid(tiles, shape, overlap=40)
+    H, W = 3 * th - 2 * 40 - 13, 2 * tw - 40 - 5              # canvas cuts the last row / column of tiles
+    b = bm.BlendingModule(num_levels=3, ssim_threshold=0.97)
+    result = b.laplacian_fusion(infos, output_shape=(H, W))
+    for (win, st) in ((16, 8), (16, 4), (12, 6)):
+        got = b.detect_seams(result, infos, window_size=win, stride=st)
+        want = onp.detect_seams(result, tiles, [(i.x, i.y) for i in infos], 0.97, win, st)
+        assert len(got) == len(want) and len(got) > 0, (win, st, len(got), len(want))
+        for g, w in zip(got, want):
+            assert (g.x, g.y, g.width, g.height) == w[:4]
+            assert g.ssim_score == pytest.approx(w[4], rel=1e-9, abs=1e-12)
+
+
 def test_rccl_world1_smoke():
     """The only RCCL exercise a one-GPU box allows (RCCL refuses two ranks on one device): a world-size-1 process group
     on backend "nccl" with device_id, as bench.py / DevicePipeline create it -- communicator creation, the 4-double
