@@ -25,22 +25,37 @@ __device__ __forceinline__ int cc_reflect101(int p, int n)
     return p;
 }
 
+// 12 bytes per thread and step (a multiple of every channel count 1..4, so byte j of a group is channel j % cn), bins
+// replicated four times per block (lane & 3): neighbouring lanes read neighbouring, mostly equal pixels, and equal values in
+// one LDS atomic serialise.
+typedef unsigned adj_u3_t __attribute__((ext_vector_type(3)));
+typedef adj_u3_t adj_u3_a1_t __attribute__((aligned(1)));
+
 __global__ __launch_bounds__(256) void k_hist_u8(const unsigned char *__restrict__ img, long long stride, int h, int w, int cn,
                                                  unsigned long long *__restrict__ hist)
 {
-    __shared__ unsigned bins[4][256];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < 4 * 256; i += 256) (&bins[0][0])[i] = 0u;
+    __shared__ unsigned bins[4][4][256];                       // [replica][channel][value]
+    const int tid = threadIdx.x, rep = tid & 3;
+    for (int i = tid; i < 4 * 4 * 256; i += 256) (&bins[0][0][0])[i] = 0u;
     __syncthreads();
-    const long long rowlen = (long long)w * cn;
+    const long long rowlen = (long long)w * cn, ngroups = rowlen / 12;
+    int ch[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) ch[j] = j % cn;
     for (int y = blockIdx.y; y < h; y += gridDim.y) {
         const unsigned char *row = img + (size_t)y * stride;
-        for (long long i = (long long)blockIdx.x * 256 + tid; i < rowlen; i += (long long)gridDim.x * 256)
-            atomicAdd(&bins[(int)(i % cn)][row[i]], 1u);
+        for (long long g = (long long)blockIdx.x * 256 + tid; g < ngroups; g += (long long)gridDim.x * 256) {
+            const adj_u3_t q = *(const __attribute__((address_space(1))) adj_u3_a1_t *)(row + g * 12);
+            const unsigned wd[3] = {q.x, q.y, q.z};
+#pragma unroll
+            for (int j = 0; j < 12; ++j) atomicAdd(&bins[rep][ch[j]][(wd[j >> 2] >> (8 * (j & 3))) & 0xFFu], 1u);
+        }
+        if (blockIdx.x == 0)                                    // the row's tail (< 12 bytes)
+            for (long long i = ngroups * 12 + tid; i < rowlen; i += 256) atomicAdd(&bins[rep][(int)(i % cn)][row[i]], 1u);
     }
     __syncthreads();
     for (int i = tid; i < cn * 256; i += 256) {
-        const unsigned v = (&bins[0][0])[i];
+        const unsigned v = ((&bins[0][0][0])[i] + (&bins[1][0][0])[i]) + ((&bins[2][0][0])[i] + (&bins[3][0][0])[i]);
         if (v) atomicAdd(&hist[i], (unsigned long long)v);
     }
 }
@@ -53,24 +68,46 @@ __global__ __launch_bounds__(256) void k_gray_moments(const unsigned char *__res
 {
     const unsigned char *base = tiles + (size_t)blockIdx.z * tile_bytes;
     unsigned long long s1 = 0, s2 = 0;
+#pragma unroll 4
     for (int y = blockIdx.y; y < h; y += gridDim.y) {
         const unsigned char *row = base + (size_t)y * stride;
-        for (int x = blockIdx.x * 256 + threadIdx.x; x < w; x += gridDim.x * 256) {
-            const int c0 = row[3 * x], c1 = row[3 * x + 1], c2 = row[3 * x + 2];
+        auto gray = [&](int c0, int c1, int c2) {
             const int r = swap_rb ? c2 : c0, b = swap_rb ? c0 : c2;
-            const int g = shift == 15 ? (r * 9798 + c1 * 19235 + b * 3735 + (1 << 14)) >> 15
-                                      : (r * 4899 + c1 * 9617 + b * 1868 + (1 << 13)) >> 14;
-            s1 += (unsigned)g;
-            s2 += (unsigned)(g * g);
+            return shift == 15 ? (r * 9798 + c1 * 19235 + b * 3735 + (1 << 14)) >> 15 : (r * 4899 + c1 * 9617 + b * 1868 + (1 << 13)) >> 14;
+        };
+        const int ngroups = w / 4;                              // four pixels = 12 bytes per thread and step
+        for (int gi = blockIdx.x * 256 + threadIdx.x; gi < ngroups; gi += gridDim.x * 256) {
+            const adj_u3_t q = *(const __attribute__((address_space(1))) adj_u3_a1_t *)(row + (size_t)gi * 12);
+            const unsigned wd[3] = {q.x, q.y, q.z};
+            unsigned t1 = 0, t2 = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i0 = 3 * k, i1 = 3 * k + 1, i2 = 3 * k + 2;
+                const int g = gray((int)((wd[i0 >> 2] >> (8 * (i0 & 3))) & 0xFFu), (int)((wd[i1 >> 2] >> (8 * (i1 & 3))) & 0xFFu),
+                                   (int)((wd[i2 >> 2] >> (8 * (i2 & 3))) & 0xFFu));
+                t1 += (unsigned)g;
+                t2 += (unsigned)(g * g);
+            }
+            s1 += t1;
+            s2 += t2;
         }
+        if (blockIdx.x == 0)
+            for (int x = ngroups * 4 + threadIdx.x; x < w; x += 256) {
+                const int g = gray(row[3 * x], row[3 * x + 1], row[3 * x + 2]);
+                s1 += (unsigned)g;
+                s2 += (unsigned)(g * g);
+            }
     }
     for (int o = 32; o > 0; o >>= 1) {
         s1 += __shfl_down(s1, o, 64);
         s2 += __shfl_down(s2, o, 64);
     }
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&sums[2 * blockIdx.z], s1);
-        atomicAdd(&sums[2 * blockIdx.z + 1], s2);
+    __shared__ unsigned long long ws[4][2];
+    if ((threadIdx.x & 63) == 0) { ws[threadIdx.x >> 6][0] = s1; ws[threadIdx.x >> 6][1] = s2; }
+    __syncthreads();
+    if (threadIdx.x < 2) {                                      // one atomic per block and moment (a few addresses take them all)
+        const unsigned long long t = (ws[0][threadIdx.x] + ws[1][threadIdx.x]) + (ws[2][threadIdx.x] + ws[3][threadIdx.x]);
+        if (t) atomicAdd(&sums[2 * blockIdx.z + threadIdx.x], t);
     }
 }
 
@@ -186,6 +223,177 @@ __global__ __launch_bounds__(256) void k_cc_apply(const unsigned char *__restric
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The guided filter at its reference setting (8 x 8 box means, blending_module.py:1110-1146) register-blocked: a thread
+// forms FOUR neighbouring window sums from eleven values it reads once (row pass: four columns of one patch row; column
+// pass: four rows of one column), and the four maps go through LDS two at a time (24 KB instead of 47 KB of row sums: four
+// blocks per CU).  Every sum still adds its eight terms in the oracle's order (left to right, top to bottom, in fp64), so
+// the result is bit-identical to the generic kernels below, which remain for other window sizes.  a / b are PLANAR
+// [c][h][w] here (coalesced in both passes).  200 MP image: 10.5 + 6.4 ms -> see DESIGN.md.
+// ---------------------------------------------------------------------------------------------------------------
+#define CC8_R 8
+#define CC8_PH (CC_TH + CC8_R - 1)        /* 23 patch rows */
+#define CC8_PW 72                         /* 71 patch columns, padded */
+#define CC8_LDS (2 * CC8_PH * CC8_PW * 4 + CC8_PH * CC_TW * 2 * 8 + 1024)
+
+// four outputs j = 0..3, each the sum of v[j .. j + 7] in that order
+__device__ __forceinline__ void cc8_sums(const double (&v)[11], double (&o)[4])
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < CC8_R; ++k) t += v[j + k];
+        o[j] = t;
+    }
+}
+
+// column pass over the row sums of one pair of maps: thread (gy, ox) -> rows 4 gy .. 4 gy + 3
+__device__ __forceinline__ void cc8_cols(const double *__restrict__ hs, int gy, int ox, double (&t0)[4], double (&t1)[4])
+{
+    double v0[11], v1[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        const double *r = hs + ((size_t)(4 * gy + k) * CC_TW + ox) * 2;
+        v0[k] = r[0];
+        v1[k] = r[1];
+    }
+    cc8_sums(v0, t0);
+    cc8_sums(v1, t1);
+}
+
+__global__ __launch_bounds__(256) void k_cc_coeff8(const unsigned char *__restrict__ img, long long stride, int h, int w, int cn,
+                                                   const float *__restrict__ glut, float eps, double scale,
+                                                   float *__restrict__ a_out, float *__restrict__ b_out)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[CC8_LDS];
+    float *g_p = (float *)smem;                                   // [PH][PW]
+    float *s_p = g_p + CC8_PH * CC8_PW;
+    double *hs = (double *)(s_p + CC8_PH * CC8_PW);               // [PH][TW][2]
+    float *lut = (float *)(hs + CC8_PH * CC_TW * 2);              // [256]
+    const int tid = threadIdx.x, anchor = CC8_R / 2;
+    const int x0 = blockIdx.x * CC_TW, y0 = blockIdx.y * CC_TH;
+    const size_t plane = (size_t)h * w;
+    for (int c = 0; c < cn; ++c) {
+        lut[tid] = glut[c * 256 + tid];
+        __syncthreads();                                          // also: the previous channel's passes are done
+        for (int e = tid; e < CC8_PH * CC8_PW; e += 256) {
+            const int py = e / CC8_PW, px = e - py * CC8_PW;
+            const int gy = cc_reflect101(y0 + py - anchor, h), gx = cc_reflect101(x0 + px - anchor, w);
+            const int v = img[(size_t)gy * stride + (size_t)gx * cn + c];
+            g_p[e] = lut[v];
+            s_p[e] = (float)v;
+        }
+        __syncthreads();
+        double keep[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};   // column sums of g and s (first pair) of this thread
+#pragma unroll
+        for (int pair = 0; pair < 2; ++pair) {
+            // row pass: item (py, gx) -> columns 4 gx .. 4 gx + 3 of patch row py; pair 0: g, s   pair 1: g * s, g * g
+            for (int e = tid; e < CC8_PH * (CC_TW / 4); e += 256) {
+                const int py = e / (CC_TW / 4), ox = (e - py * (CC_TW / 4)) * 4;
+                double v0[11], v1[11];
+#pragma unroll
+                for (int k = 0; k < 11; ++k) {
+                    const float g = g_p[py * CC8_PW + ox + k], sv = s_p[py * CC8_PW + ox + k];
+                    v0[k] = pair == 0 ? (double)g : (double)(g * sv);
+                    v1[k] = pair == 0 ? (double)sv : (double)(g * g);
+                }
+                double o0[4], o1[4];
+                cc8_sums(v0, o0);
+                cc8_sums(v1, o1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    double *o = hs + ((size_t)py * CC_TW + ox + j) * 2;
+                    o[0] = o0[j];
+                    o[1] = o1[j];
+                }
+            }
+            __syncthreads();
+            const int gy = tid >> 6, ox = tid & 63;               // column pass: 4 x 64 items = the block
+            double t0[4], t1[4];
+            cc8_cols(hs, gy, ox, t0, t1);
+            if (pair == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { keep[0][j] = t0[j]; keep[1][j] = t1[j]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int y = y0 + 4 * gy + j, x = x0 + ox;
+                    if (y >= h || x >= w) continue;
+                    const float mg = (float)(keep[0][j] * scale), ms = (float)(keep[1][j] * scale);
+                    const float mgs = (float)(t0[j] * scale), mgg = (float)(t1[j] * scale);
+                    const float cov = mgs - mg * ms, var = mgg - mg * mg;
+                    const float a = cov / (var + eps);
+                    const float b = ms - a * mg;
+                    a_out[c * plane + (size_t)y * w + x] = a;
+                    b_out[c * plane + (size_t)y * w + x] = b;
+                }
+            }
+            __syncthreads();                                      // hs is free for the next pair / channel
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cc_apply8(const unsigned char *__restrict__ img, long long stride, int h, int w, int cn,
+                                                   const float *__restrict__ glut, double scale, const float *__restrict__ a_in,
+                                                   const float *__restrict__ b_in, unsigned char *__restrict__ out, long long ostride)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[CC8_LDS];
+    float *a_p = (float *)smem;
+    float *b_p = a_p + CC8_PH * CC8_PW;
+    double *hs = (double *)(b_p + CC8_PH * CC8_PW);
+    float *lut = (float *)(hs + CC8_PH * CC_TW * 2);
+    const int tid = threadIdx.x, anchor = CC8_R / 2;
+    const int x0 = blockIdx.x * CC_TW, y0 = blockIdx.y * CC_TH;
+    const size_t plane = (size_t)h * w;
+    for (int c = 0; c < cn; ++c) {
+        lut[tid] = glut[c * 256 + tid];
+        __syncthreads();
+        for (int e = tid; e < CC8_PH * CC8_PW; e += 256) {
+            const int py = e / CC8_PW, px = e - py * CC8_PW;
+            const int gy = cc_reflect101(y0 + py - anchor, h), gx = cc_reflect101(x0 + px - anchor, w);
+            const size_t o = c * plane + (size_t)gy * w + gx;
+            a_p[e] = a_in[o];
+            b_p[e] = b_in[o];
+        }
+        __syncthreads();
+        for (int e = tid; e < CC8_PH * (CC_TW / 4); e += 256) {
+            const int py = e / (CC_TW / 4), ox = (e - py * (CC_TW / 4)) * 4;
+            double v0[11], v1[11];
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                v0[k] = (double)a_p[py * CC8_PW + ox + k];
+                v1[k] = (double)b_p[py * CC8_PW + ox + k];
+            }
+            double o0[4], o1[4];
+            cc8_sums(v0, o0);
+            cc8_sums(v1, o1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                double *o = hs + ((size_t)py * CC_TW + ox + j) * 2;
+                o[0] = o0[j];
+                o[1] = o1[j];
+            }
+        }
+        __syncthreads();
+        const int gy = tid >> 6, ox = tid & 63;
+        double ta[4], tb[4];
+        cc8_cols(hs, gy, ox, ta, tb);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int y = y0 + 4 * gy + j, x = x0 + ox;
+            if (y >= h || x >= w) continue;
+            const float ma = (float)(ta[j] * scale), mb = (float)(tb[j] * scale);
+            const float g = lut[img[(size_t)y * stride + (size_t)x * cn + c]];
+            const float r = ma * g + mb;
+            const float cl = r < 0.0f ? 0.0f : (r > 255.0f ? 255.0f : r);
+            out[(size_t)y * ostride + (size_t)x * cn + c] = (unsigned char)cl;
+        }
+        __syncthreads();
+    }
+}
+
 // no local filter: out = u8(clip(glut[c][v], 0, 255))
 __global__ __launch_bounds__(256) void k_cc_map(const unsigned char *__restrict__ img, long long stride, int h, long long rowlen,
                                                 int cn, const float *__restrict__ glut, unsigned char *__restrict__ out,
@@ -198,9 +406,26 @@ __global__ __launch_bounds__(256) void k_cc_map(const unsigned char *__restrict_
         tab[i] = (unsigned char)cl;
     }
     __syncthreads();
-    for (int y = blockIdx.y; y < h; y += gridDim.y)
-        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < rowlen; i += (long long)gridDim.x * 256)
-            out[(size_t)y * ostride + i] = tab[(int)(i % cn) * 256 + img[(size_t)y * stride + i]];
+    const long long ngroups = rowlen / 12;                     // 12 bytes per thread and step: byte j of a group is channel j % cn
+    int ch[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) ch[j] = (j % cn) * 256;
+    for (int y = blockIdx.y; y < h; y += gridDim.y) {
+        const unsigned char *row = img + (size_t)y * stride;
+        unsigned char *orow = out + (size_t)y * ostride;
+        for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += (long long)gridDim.x * 256) {
+            const adj_u3_t q = *(const __attribute__((address_space(1))) adj_u3_a1_t *)(row + g * 12);
+            const unsigned wd[3] = {q.x, q.y, q.z};
+            unsigned o[3] = {0u, 0u, 0u};
+#pragma unroll
+            for (int j = 0; j < 12; ++j) o[j >> 2] |= (unsigned)tab[ch[j] + ((wd[j >> 2] >> (8 * (j & 3))) & 0xFFu)] << (8 * (j & 3));
+            adj_u3_t v;
+            v.x = o[0]; v.y = o[1]; v.z = o[2];
+            *(__attribute__((address_space(1))) adj_u3_a1_t *)(orow + g * 12) = v;
+        }
+        if (blockIdx.x == 0)
+            for (long long i = ngroups * 12 + threadIdx.x; i < rowlen; i += 256) orow[i] = tab[(int)(i % cn) * 256 + row[i]];
+    }
 }
 
 }  // namespace
@@ -243,7 +468,8 @@ int sr_gray_moments_u8(sr_ctx *ctx, const uint8_t *d_tiles, int n, int64_t tile_
     HIPCHK(hipMemsetAsync(scr, 0, (size_t)n * 2 * sizeof(unsigned long long), ctx->stream));
     {
         ProfScope ps(ctx, "gray_moments");
-        dim3 grid((unsigned)std::min((w + 255) / 256, 8), (unsigned)std::min(h, 64), (unsigned)n);
+        // four pixels per thread and step, one pair of atomics per block
+        dim3 grid((unsigned)std::max(std::min((w / 4 + 255) / 256, 8), 1), (unsigned)std::min(h, 128), (unsigned)n);
         hipLaunchKernelGGL(k_gray_moments, grid, dim3(256), 0, ctx->stream, d_tiles, (long long)tile_bytes, (long long)stride, h, w,
                            gray_shift, swap_rb ? 1 : 0, (unsigned long long *)scr);
     }
@@ -293,15 +519,28 @@ int sr_color_correct_u8(sr_ctx *ctx, const uint8_t *d_img, int64_t stride, int h
         (void)hipFuncSetAttribute((const void *)k_cc_coeff, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
         (void)hipFuncSetAttribute((const void *)k_cc_apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
     }
-    {
-        ProfScope ps(ctx, "guided_coeff");
-        hipLaunchKernelGGL(k_cc_coeff, grid, dim3(256), lds1, ctx->stream, d_img, (long long)stride, h, w, cn, (const float *)d_glut,
-                           radius, eps, scale, d_a, d_b);
-    }
-    {
-        ProfScope ps(ctx, "guided_apply");
-        hipLaunchKernelGGL(k_cc_apply, grid, dim3(256), lds2, ctx->stream, d_img, (long long)stride, h, w, cn, (const float *)d_glut,
-                           radius, scale, (const float *)d_a, (const float *)d_b, d_out, (long long)out_stride);
+    if (radius == CC8_R) {                      // the reference's setting: register-blocked kernels, planar a / b
+        {
+            ProfScope ps(ctx, "guided_coeff");
+            hipLaunchKernelGGL(k_cc_coeff8, grid, dim3(256), 0, ctx->stream, d_img, (long long)stride, h, w, cn, (const float *)d_glut, eps,
+                               scale, d_a, d_b);
+        }
+        {
+            ProfScope ps(ctx, "guided_apply");
+            hipLaunchKernelGGL(k_cc_apply8, grid, dim3(256), 0, ctx->stream, d_img, (long long)stride, h, w, cn, (const float *)d_glut, scale,
+                               (const float *)d_a, (const float *)d_b, d_out, (long long)out_stride);
+        }
+    } else {
+        {
+            ProfScope ps(ctx, "guided_coeff");
+            hipLaunchKernelGGL(k_cc_coeff, grid, dim3(256), lds1, ctx->stream, d_img, (long long)stride, h, w, cn, (const float *)d_glut,
+                               radius, eps, scale, d_a, d_b);
+        }
+        {
+            ProfScope ps(ctx, "guided_apply");
+            hipLaunchKernelGGL(k_cc_apply, grid, dim3(256), lds2, ctx->stream, d_img, (long long)stride, h, w, cn, (const float *)d_glut,
+                               radius, scale, (const float *)d_a, (const float *)d_b, d_out, (long long)out_stride);
+        }
     }
     rc = check_launch("color_correct");
     hipError_t es = stream_sync(ctx);

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Device time of the colour-correction kernels (blending_module.color_correction: 256-bin histograms, LUT apply, guided
+filter) and the complexity-score moments on one 200 MP image / on the 25 tiles of the 200 MP workload.
+usage (GPU box): python tools/adjust_timing.py"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "super-resolution-system_amd")):
+    sys.path.insert(0, p)
+import numpy as np            # noqa: E402
+import torch                  # noqa: E402
+import _native                # noqa: E402
+import device_pipeline as dp  # noqa: E402
+
+geo = dp.workload_geometry("200MP")
+H, W, cn = geo.canvas_h, geo.canvas_w, 3
+dev = torch.device("cuda", 0)
+ctx = _native.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+g = torch.Generator(device=dev).manual_seed(3)
+img = torch.randint(0, 256, (H, W * cn), dtype=torch.uint8, device=dev, generator=g)
+out = torch.empty_like(img)
+lut = np.tile(np.arange(256, dtype=np.float32), (cn, 1))
+tw, th = geo.rects[0][2], geo.rects[0][3]
+tiles = torch.randint(0, 256, (len(geo.rects), th, tw * cn), dtype=torch.uint8, device=dev, generator=g)
+
+
+def run():
+    ctx.histogram_u8(img.data_ptr(), W * cn, H, W, cn)
+    ctx.color_correct_u8(img.data_ptr(), W * cn, H, W, cn, lut, False, 8, 1e-3, out.data_ptr(), W * cn)
+    ctx.color_correct_u8(img.data_ptr(), W * cn, H, W, cn, lut, True, 8, 1e-3, out.data_ptr(), W * cn)
+    ctx.gray_std_u8(tiles.data_ptr(), len(geo.rects), th * tw * cn, tw * cn, th, tw)
+
+
+run()
+torch.cuda.synchronize()
+ctx.prof_enable(True)
+ctx.prof_reset()
+run()
+torch.cuda.synchronize()
+print(json.dumps({"image": f"{W}x{H}", "tiles": f"{len(geo.rects)} x {tw}x{th}",
+                  "kernel_ms": {k: round(ms, 3) for k, (ms, n) in ctx.prof_get().items()},
+                  "bytes_GB": {"histogram": round(H * W * cn / 1e9, 3), "lut_apply": round(2 * H * W * cn / 1e9, 3)}}))
