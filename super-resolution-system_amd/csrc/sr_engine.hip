@@ -1720,7 +1720,9 @@ template <int CN>
 __device__ __forceinline__ void cubic_sample(const unsigned char *__restrict__ src, long long sstride, int sh, int sw,
                                              const CubicTab X, const CubicTab Y, int (&out)[CN])
 {
-    long long acc[CN];
+    // 32-bit accumulators suffice: the cubic's taps (a = -0.75) have sum |c| <= 1.375, i.e. <= 2817 in 1/2048 units per
+    // axis, so |acc| <= 255 * 2817^2 = 2.02e9 < 2^31 -- also after the rounding constant
+    int acc[CN];
 #pragma unroll
     for (int c = 0; c < CN; ++c) acc[c] = 0;
     const bool inner = X.ofs - 1 >= 0 && X.ofs + 2 <= sw - 1;
@@ -1745,13 +1747,13 @@ __device__ __forceinline__ void cubic_sample(const unsigned char *__restrict__ s
 #pragma unroll
         for (int c = 0; c < CN; ++c) {
             const int hs = v[0][c] * X.c[0] + v[1][c] * X.c[1] + v[2][c] * X.c[2] + v[3][c] * X.c[3];
-            acc[c] += (long long)hs * yc[ky];
+            acc[c] += hs * (int)yc[ky];
         }
     }
 #pragma unroll
     for (int c = 0; c < CN; ++c) {
-        const long long t = (acc[c] + (1 << 21)) >> 22;
-        out[c] = (int)(t < 0 ? 0 : (t > 255 ? 255 : t));
+        const int t = (acc[c] + (1 << 21)) >> 22;
+        out[c] = t < 0 ? 0 : (t > 255 ? 255 : t);
     }
 }
 
