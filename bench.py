@@ -238,12 +238,24 @@ def run_workload(args, workload: str, steps: int, warmup: int, detailed: bool, d
     # the tile stage and pyramids of image i+1 (fp64-VALU-bound next to bandwidth-bound work), and for N > 1 the tile
     # stage + exchange of image i+1 are posted as soon as image i's rows have arrived, so the xGMI transfer runs under
     # the blend of image i.  Every image goes through every stage inside the timed region.
+    lp_model, lp_value = None, None
+    if args.lpips != "none":
+        if world > 1 and not batch:
+            raise SystemExit("--lpips needs one GPU or --mode batch (a strip owner holds only its rows of the canvas)")
+        import _native
+        lp_model = _native.LpipsModel(ctx, args.lpips, _native.lpips_synthetic_weights(args.lpips))
+
     def run_steps(k):
+        nonlocal lp_value
         if k <= 0:
             return
         pipe.pipeline_begin(image)
         for i in range(k):
             pipe.pipeline_step(reference, image if i + 1 < k else None)
+            if lp_model is not None:                     # synchronous (returns the layer sums): ends the overlap for this image
+                torch.cuda.current_stream(dev).synchronize()
+                lp_value = lp_model.value(reference.data_ptr(), reference.stride(0), pipe.canvas.data_ptr(), pipe.canvas.stride(0),
+                                          H, W, cn)
             if evs is not None:
                 evs[i + 1].record()
         pipe.pipeline_finish()
@@ -347,6 +359,9 @@ def run_workload(args, workload: str, steps: int, warmup: int, detailed: bool, d
                         "max": round(step_ms[-1], 4), "clock": "HIP events on the main stream between consecutive images, rank 0"},
             "quality": {k: (v if np.isfinite(v) else str(v)) for k, v in metrics.items()},
         }
+        if lp_model is not None:
+            out["config"]["workload"] += f" + LPIPS-{args.lpips} (synthetic weights, parity unpinned)"
+            out["quality"][f"lpips_{args.lpips}_synthetic_weights"] = lp_value
         if detailed:
             kernels = {}
             for name, (ms, launches) in prof.items():
@@ -435,6 +450,10 @@ def main() -> int:
     ap.add_argument("--no-pcie", action="store_true",
                     help="skip the host->device (inputs) / device->host (canvas) timing that N=1 runs report beside the resident rate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lpips", default="none", choices=["none", "alex", "vgg"],
+                    help="BASELINE config 5 whole: add LPIPS(canvas, reference) of this backbone to every timed image (seeded "
+                         "synthetic weights -- the pretrained ones are not available offline; timing does not depend on their "
+                         "values); one GPU or batch mode only.  Not part of the default line.")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-kernel HIP-event timing")
     args = ap.parse_args()
 

@@ -866,6 +866,19 @@ def lpips_pack_weights(net: str, weights: dict):
     return convs_w, convs_b, lins, shift, scale
 
 
+def lpips_synthetic_weights(net: str, seed: int = 20260313) -> dict:
+    """Seeded random weights of the real shapes (He-scaled convolutions, non-negative 1x1 `lin` layers) for timing and
+    structural tests: the pretrained LPIPS weights cannot be fetched offline.  NOT a substitute for them."""
+    rng = np.random.default_rng(seed)
+    w = {}
+    for key, (co, ci, k) in zip(LPIPS_CONV_KEYS[net], LPIPS_CONV_SHAPES[net]):
+        w[key + ".weight"] = (rng.standard_normal((co, ci, k, k)) * np.sqrt(2.0 / (ci * k * k))).astype(np.float32)
+        w[key + ".bias"] = rng.uniform(0, 0.1, co).astype(np.float32)
+    for i, c in enumerate(LPIPS_TAP_CHANNELS[net]):
+        w[f"lin{i}.model.1.weight"] = rng.uniform(0, 2.0 / c, (1, c, 1, 1)).astype(np.float32)
+    return w
+
+
 class LpipsModel:
     """sr_lpips_model: one backbone + lin layers resident on the GPU."""
 

@@ -22,14 +22,7 @@ F32_MATRIX_PEAK_TFLOPS = 157.3
 
 def synthetic_weights(net, seed=20260313):
     import _native
-    rng = np.random.default_rng(seed)
-    w = {}
-    for key, (co, ci, k) in zip(_native.LPIPS_CONV_KEYS[net], _native.LPIPS_CONV_SHAPES[net]):
-        w[key + ".weight"] = (rng.standard_normal((co, ci, k, k)) * np.sqrt(2.0 / (ci * k * k))).astype(np.float32)
-        w[key + ".bias"] = rng.uniform(0, 0.1, co).astype(np.float32)
-    for i, c in enumerate(_native.LPIPS_TAP_CHANNELS[net]):
-        w[f"lin{i}.model.1.weight"] = rng.uniform(0, 2.0 / c, (1, c, 1, 1)).astype(np.float32)
-    return w
+    return _native.lpips_synthetic_weights(net, seed)
 
 
 def conv_flops(net, h, w):
