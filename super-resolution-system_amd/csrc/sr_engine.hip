@@ -2383,8 +2383,10 @@ __global__ __launch_bounds__(256) void k_feather_merge(const MergeDev *__restric
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float wv = wacc[k] > 1e-6f ? wacc[k] : 1e-6f;
+        float q[3];
+        div_shared<3>(acc[k], wv, q);             // the IEEE quotients, one reciprocal per pixel (see the final gather)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) ob[3 * k + c] = (unsigned)(unsigned char)(int)(acc[k][c] / wv);   // astype(uint8): truncation, no clip
+        for (int c = 0; c < 3; ++c) ob[3 * k + c] = (unsigned)(unsigned char)(int)q[c];   // astype(uint8): truncation, no clip
     }
     unsigned char *o = canvas + (size_t)y * cstride + (size_t)x0 * 3;
     if (nx == 4 && ((cstride & 3) == 0) && ((((size_t)canvas) & 3) == 0)) {
