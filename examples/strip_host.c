@@ -69,7 +69,7 @@ int main(int argc, char **argv)
     OK(sr_exchange_plan(rects, N, CN, LEVELS, H, W, world, HALO, SR_OWNER_BALANCED, bounds, rows, need, owner));
 
     /* tile stage: a rank cuts only the tiles it owns */
-    void *d_tile[N] = {0}, *d_recv[N] = {0}, *d_blend[N] = {0};
+    void *d_tile[N] = {0}, *d_recv[N] = {0};
     const void *d_owned[N] = {0};
     int64_t strides[N];
     int own_xywh[N * 4], n_own = 0;
@@ -82,10 +82,9 @@ int main(int argc, char **argv)
             OK(sr_dev_alloc(ctx, (size_t)TILE * TILE * CN, &d_tile[t]));
             memcpy(&own_xywh[4 * n_own], &xywh[4 * t], 4 * sizeof(int));
             own_ptr[n_own] = d_tile[t]; own_stride[n_own] = strides[t]; ++n_own;
-            d_owned[t] = d_tile[t]; d_blend[t] = d_tile[t];
+            d_owned[t] = d_tile[t];
         } else if (r0 < r1) {                       /* rows this strip needs of a tile another rank owns */
             OK(sr_dev_alloc(ctx, (size_t)(r1 - r0) * TILE * CN, &d_recv[t]));
-            d_blend[t] = (char *)d_recv[t] - (int64_t)r0 * strides[t];          /* virtual row 0 */
         }
     }
     if (n_own) OK(sr_tile_extract(ctx, (const uint8_t *)d_img, H, W, CN, stride, own_xywh, n_own, own_ptr, own_stride));
@@ -111,12 +110,12 @@ int main(int argc, char **argv)
     }
     sr_comm *comm;
     OK(sr_comm_init(ctx, id, world, rank, &comm));
-    OK(sr_comm_exchange_tile_rows(ctx, comm, rects, N, CN, need, owner, d_owned, strides, d_recv));
 
-    /* blend this rank's rows, assess its strip, reduce */
+    /* exchange + blend of this rank's rows (one call; sr_comm_exchange_tile_rows + sr_laplacian_blend are its two halves),
+     * then assess its strip and reduce */
     sr_blend_plan *plan;
     OK(sr_blend_plan_create(ctx, rects, N, CN, H, W, LEVELS, SR_W_COSINE, rows[2 * rank], rows[2 * rank + 1], &plan));
-    OK(sr_laplacian_blend(plan, SR_U8, d_blend, strides, (uint8_t *)d_canvas, stride, NULL));
+    OK(sr_laplacian_blend_sharded(ctx, comm, plan, rects, N, CN, need, owner, d_owned, strides, d_recv, (uint8_t *)d_canvas, stride));
     OK(sr_assess_u8_async(ctx, (const uint8_t *)d_ref, stride, (const uint8_t *)d_canvas, stride, H, W, CN, 15, 255.0, bounds[rank],
                           bounds[rank + 1], SR_ASSESS_ALL, (sr_assess_sums *)d_sums));
     OK(sr_comm_allreduce_f64(ctx, comm, (double *)d_sums, 4));

@@ -205,6 +205,13 @@ SR_API int sr_comm_exchange(sr_ctx *ctx, sr_comm *comm, const sr_xfer *sends, in
 SR_API int sr_comm_exchange_tile_rows(sr_ctx *ctx, sr_comm *comm, const sr_tile_rect *h_tiles, int n, int cn,
                                       const int *h_need, const int *h_owner, const void *const *d_owned,
                                       const int64_t *owned_stride, void *const *d_recv);
+/* SURVEY 8(b)'s sr_laplacian_blend_sharded: sr_comm_exchange_tile_rows followed, on the same stream, by sr_laplacian_blend of
+ * this rank's rows -- plan = sr_blend_plan_create(..., rows[2 rank], rows[2 rank + 1]) of the exchange plan, the received
+ * windows addressed through virtual base pointers.  (A host that wants the exchange of image i + 1 under the blend of image
+ * i issues the two calls itself on two streams, as device_pipeline.py does.) */
+SR_API int sr_laplacian_blend_sharded(sr_ctx *ctx, sr_comm *comm, sr_blend_plan *plan, const sr_tile_rect *h_tiles, int n, int cn,
+                                      const int *h_need, const int *h_owner, const void *const *d_owned,
+                                      const int64_t *strides, void *const *d_recv, uint8_t *d_canvas, int64_t canvas_stride);
 /* host only: the batch sr_comm_exchange_tile_rows posts, for hosts that move the rows themselves (MPI, hipMemcpyPeer).
  * Sends in (reader, tile) order, receives in (owner, tile) order; *n_send / *n_recv are the counts needed (SR_ERR_SHAPE when
  * the arrays are too small: at most n * (world - 1) sends and n receives). */

@@ -108,6 +108,8 @@ SIGNATURES = {
     "sr_comm_exchange_tile_rows": (_i, [_vp, _vp, C.POINTER(TileRect), _i, _i, _pi, _pi, C.POINTER(_vp), C.POINTER(_i64),
                                         C.POINTER(_vp)]),
     "sr_comm_allreduce_f64": (_i, [_vp, _vp, _vp, _i]),
+    "sr_laplacian_blend_sharded": (_i, [_vp, _vp, _vp, C.POINTER(TileRect), _i, _i, _pi, _pi, C.POINTER(_vp), C.POINTER(_i64),
+                                        C.POINTER(_vp), _vp, _i64]),
     "sr_exchange_xfers": (_i, [C.POINTER(TileRect), _i, _i, _i, _i, _pi, _pi, C.POINTER(_vp), C.POINTER(_i64), C.POINTER(_vp),
                                C.POINTER(Xfer), _i, _pi, C.POINTER(Xfer), _i, _pi]),
     "sr_strip_bounds": (_i, [C.POINTER(TileRect), _i, _i, _i, _i, _i, _pi]),

@@ -219,6 +219,25 @@ int sr_comm_exchange_tile_rows(sr_ctx *ctx, sr_comm *comm, const sr_tile_rect *h
     return sr_comm_exchange(ctx, comm, sends.data(), ns, recvs.data(), nr);
 }
 
+int sr_laplacian_blend_sharded(sr_ctx *ctx, sr_comm *comm, sr_blend_plan *plan, const sr_tile_rect *h_tiles, int n, int cn,
+                               const int *h_need, const int *h_owner, const void *const *d_owned, const int64_t *strides,
+                               void *const *d_recv, uint8_t *d_canvas, int64_t canvas_stride)
+{
+    if (!comm || !plan || !h_tiles || !h_need || !h_owner || !d_owned || !strides || !d_recv || n < 1)
+        return sr_set_error(SR_ERR_INVALID_ARG, "sr_laplacian_blend_sharded: bad arguments");
+    int rc = sr_comm_exchange_tile_rows(ctx, comm, h_tiles, n, cn, h_need, h_owner, d_owned, strides, d_recv);
+    if (rc) return rc;
+    // tile base pointers as the blend wants them: an owned tile as it is, a received window moved up to its (virtual) row 0
+    std::vector<void *> base((size_t)n, nullptr);
+    for (int t = 0; t < n; ++t) {
+        const int r0 = h_need[((size_t)comm->rank * n + t) * 2], r1 = h_need[((size_t)comm->rank * n + t) * 2 + 1];
+        if (h_owner[t] == comm->rank) base[(size_t)t] = (void *)d_owned[t];
+        else if (r0 < r1) base[(size_t)t] = (char *)d_recv[t] - (int64_t)r0 * strides[t];
+    }
+    // same stream as the exchange: the blend starts when the rows have arrived
+    return sr_laplacian_blend(plan, SR_U8, base.data(), strides, d_canvas, canvas_stride, nullptr);
+}
+
 int sr_comm_allreduce_f64(sr_ctx *ctx, sr_comm *comm, double *d_buf, int count)
 {
     if (!comm || !d_buf || count < 1) return sr_set_error(SR_ERR_INVALID_ARG, "sr_comm_allreduce_f64: bad arguments");
