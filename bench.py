@@ -66,29 +66,49 @@ def algorithmic_bytes(geo) -> dict:
     }
 
 
-# bench kernel family -> rocprofv3 kernel name (profiles/*_traffic.json)
-ROCPROF_NAMES = {"tile_extract": "k_tile_extract", "down_l0": "k_down_march<0, 3>",
-                 "down_l1p": "k_down_march<2, 3>",
-                 "up_level": "k_up_level_blk<3>", "final_gather": "k_final_fast<0, true, 3>",
-                 "assess_all": "k_assess_march<3, false, true, true, true>"}
+# bench kernel family -> prefix of the rocprofv3 kernel name(s) (template arguments change between builds: matched by prefix)
+ROCPROF_PREFIXES = {"tile_extract": ["k_tile_extract"], "down_l0": ["k_down_march<0,"], "down_l1p": ["k_down_march<2,"],
+                    "up_level": ["k_up_level_blk<"], "final_gather": ["k_final_fast<", "k_final_fused<"],
+                    "assess_all": ["k_assess_march<"]}
+BLEND_FAMILIES = ("down_l0", "down_l1p", "up_level", "final_gather")
+# fp64 VALU model of the fused assessment: per pixel (= per thread and row) the march issues 118
+# instructions at the fp64 rate (16 lanes / clock / SIMD: 4 cycles per wave) and 105 at the fp32 rate (2 cycles).
+ASSESS_FP64_INSTR_PER_PX, ASSESS_FP32_INSTR_PER_PX = 118, 105
+GPU_SIMDS, GPU_CLOCK_HZ = 256 * 4, 2.4e9
+
+
+def family_of(kernel_name: str):
+    k = kernel_name.replace("void ", "")
+    for fam, prefixes in ROCPROF_PREFIXES.items():
+        if any(k.startswith(p) for p in prefixes):
+            return fam
+    return None
 
 
 def measured_traffic() -> dict:
-    """HBM bytes per step and kernel family from the newest committed PMC summary (tools/summarize_profiles.py:
-    FETCH_SIZE / WRITE_SIZE in their own rocprofv3 passes, read side calibrated on the pure-copy kernel)."""
+    """HBM bytes per LAUNCH SET (all launches of the family in one step) from the newest committed PMC summary
+    (tools/summarize_profiles.py: FETCH_SIZE / WRITE_SIZE in their own rocprofv3 passes; `total_2x` = reads doubled as
+    MI355X_MICROARCH.md prescribes for gfx950, `total` = reads scaled by the factor calibrated on the pure-copy kernel)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
-    if not files:
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))      # rNN_<letter>_traffic.json: name order
+    data = None
+    while files and data is None:
+        cand = json.load(open(files[-1]))
+        if cand.get("format") == 2:                       # per-launch records (round 3 on); older summaries are not read
+            data = cand
+        else:
+            files.pop()
+    if data is None:
         return {}
-    data = json.load(open(files[-1]))
-    out = {}
-    for fam, names in ROCPROF_NAMES.items():
-        names = names if isinstance(names, list) else [names]
-        vals = [data["kernels"][n]["total"] for n in names if n in data.get("kernels", {})]
-        if vals:
-            out[fam] = sum(vals)
-    out["_source"] = os.path.basename(files[-1])
-    out["_note"] = data.get("note")
+    out = {"_source": os.path.basename(files[-1]), "_note": data.get("note"), "_build_digest": data.get("build_digest")}
+    for name, rec in data.get("kernels", {}).items():
+        fam = family_of(name)
+        if fam is None:
+            continue
+        acc = out.setdefault(fam, {"total": 0.0, "total_2x": 0.0, "launches_per_step": 0.0})
+        acc["total"] += rec["per_step"]["total"]
+        acc["total_2x"] += rec["per_step"]["total_2x"]
+        acc["launches_per_step"] += rec["launches_per_step"]
     return out
 
 
@@ -117,13 +137,16 @@ def cpu_baseline(seed_img: np.ndarray, geo_full, budget_tiles=(3, 3), repeats: i
         canvas = oc.laplacian_fusion(tiles, [(y, x) for (x, y, _, _) in rects], (H, W), geo_full.levels,
                                      geo_full.weight_type)                                          # blend
         t2 = time.perf_counter()
-        oc.psnr(ref, canvas)                                                                        # QA
+        scores = {"psnr": oc.psnr(ref, canvas)}                                                     # QA
         g1, g2 = oc.rgb2gray_u8(ref), oc.rgb2gray_u8(canvas)
         for mode in ("uniform", "gauss", "simple"):
-            oc.ssim(g1, g2, mode)
+            scores[f"ssim_{mode}"] = oc.ssim(g1, g2, mode)
         t3 = time.perf_counter()
+        keep.update(img=img, ref=ref, canvas=canvas, scores=scores, rows=rows, cols=cols,
+                    grid=dict(tile_w=tw, tile_h=th, rows=rows, cols=cols, ov_x=tw - step_x, ov_y=th - step_y))
         return W, H, (t1 - t0, t2 - t1, t3 - t2)
 
+    keep = {}
     rows, cols = min(budget_tiles[0], len(geo_full.rects) // max(ncols_full, 1)), min(budget_tiles[1], ncols_full)
     one(min(2, rows), min(2, cols))                                      # warm-up, not reported
     runs = [one(rows, cols) for _ in range(max(1, repeats))]
@@ -131,12 +154,40 @@ def cpu_baseline(seed_img: np.ndarray, geo_full, budget_tiles=(3, 3), repeats: i
     totals = sorted(sum(r[2]) for r in runs)
     med = min(runs, key=lambda r: abs(sum(r[2]) - totals[len(totals) // 2]))[2]
     mp = W * H / 1e6
-    return {"value": mp / sum(med), "unit": "MP/s", "cores": oc.num_threads(), "kind": "port",
+    return keep, {"value": mp / sum(med), "unit": "MP/s", "cores": oc.num_threads(), "kind": "port",
             "omp_num_threads_env": os.environ.get("OMP_NUM_THREADS"), "host_cpus": os.cpu_count(),
             "runs_s": [round(t, 3) for t in totals], "statistic": f"median of {len(runs)} runs after 1 warm-up",
             "sample": f"{rows}x{cols} corner of the tile grid ({W}x{H} = {mp:.1f} MP canvas, tiles {tw}x{th}): "
                       f"extract {med[0]:.2f}s + laplacian blend {med[1]:.2f}s + PSNR/3xSSIM {med[2]:.2f}s; "
                       f"oracle/sr_oracle.c with OpenMP (restated reference CPU path, cv2/skimage absent)"}
+
+
+def parity_vs_oracle(sample: dict, geo_full, device_index: int) -> dict:
+    """The CHECK that goes with cpu_baseline (outside every timed region): the oracle's sample -- the same corner of the
+    tile grid, same inputs -- through the HIP pipeline object, canvas compared byte for byte, PSNR for equality, the three
+    SSIM variants by relative error.  (Full-size comparisons of every BASELINE config: tests/test_gpu_fullsize.py.)"""
+    import torch
+    import device_pipeline as dp
+    geo = dp.grid_geometry(levels=geo_full.levels, weight_type=geo_full.weight_type, **sample["grid"])
+    H, W = geo.canvas_h, geo.canvas_w
+    assert sample["canvas"].shape == (H, W, 3)
+    pipe = dp.DevicePipeline(geo, 0, 1, device_index)
+    d_img = torch.from_numpy(sample["img"].reshape(H, W * 3)).to(pipe.dev)
+    d_ref = torch.from_numpy(sample["ref"].reshape(H, W * 3)).to(pipe.dev)
+    pipe.step(d_img, d_ref)
+    torch.cuda.synchronize()
+    got = pipe.canvas.cpu().numpy().reshape(H, W, 3)
+    m = pipe.metrics()
+    pipe.close()
+    want = sample["scores"]
+    ndiff = int(np.count_nonzero(got != sample["canvas"]))
+    rel = {k: abs(m[k] - want[k]) / max(abs(want[k]), 1e-300) for k in ("ssim_uniform", "ssim_gauss", "ssim_simple")}
+    return {"canvas_equal": ndiff == 0, "canvas_bytes_differing": ndiff, "canvas_bytes": int(got.size),
+            "psnr_equal": m["psnr"] == want["psnr"], "psnr_gpu": m["psnr"], "psnr_oracle": want["psnr"],
+            "ssim_rel_err": max(rel.values()), "ssim_rel_err_by_mode": rel, "ssim_tolerance": 1e-9,
+            "sample": f"{sample['rows']}x{sample['cols']} corner of the tile grid, {W}x{H} canvas "
+                      f"({W * H / 1e6:.1f} MP): HIP pipeline vs oracle/sr_oracle.c on the same inputs, outside the timed region",
+            "oracle": "restated reference CPU path; its OpenCV-defined semantics are parity-unpinned (DESIGN.md 2)"}
 
 
 def _launch_ranks(n: int, argv) -> int:
@@ -293,6 +344,17 @@ def run_workload(args, workload: str, steps: int, warmup: int, detailed: bool, d
     step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
     prof_timed = {} if no_prof else prof_ctl.get()               # the dominant kernel, inside the timed region
     prof, prof_steps = {}, max(1, min(steps, 5))
+    # one image at a time, nothing overlapped, no per-kernel events: what an isolated image costs (the image stream above
+    # hides the assessment of image i under the pyramids of image i+1)
+    latency_single = None
+    if detailed:
+        pipe.step(image, reference)
+        torch.cuda.synchronize()
+        tl = time.perf_counter()
+        for _ in range(prof_steps):
+            pipe.step(image, reference)
+        torch.cuda.synchronize()
+        latency_single = round(1e3 * (time.perf_counter() - tl) / prof_steps, 4)
     if not no_prof:
         # every family, in its own pass after the timed region, one image at a time on one stream (step()): standalone
         # kernel durations -- in the timed region the assessment shares the GPU with the next image's pyramids
@@ -364,11 +426,11 @@ def run_workload(args, workload: str, steps: int, warmup: int, detailed: bool, d
             out["quality"][f"lpips_{args.lpips}_synthetic_weights"] = lp_value
         if detailed:
             kernels = {}
+            share = 1.0 / world if (world > 1 and not batch) else 1.0         # each rank moves ~1/N of the bytes (+ halo)
             for name, (ms, launches) in prof.items():
                 nsteps = prof_steps
                 per_step_ms = ms / nsteps
                 b = alg.get(name)
-                share = 1.0 / world if (world > 1 and not batch) else 1.0     # each rank moves ~1/N of the bytes (+ halo)
                 kernels[name] = {"ms_per_step": round(per_step_ms, 4), "launches_per_step": launches / nsteps,
                                  "timed_in": "separate sequential pass (standalone)",
                                  "alg_GB": None if b is None else round(b * share / 1e9, 4),
@@ -379,31 +441,60 @@ def run_workload(args, workload: str, steps: int, warmup: int, detailed: bool, d
             if cands:
                 _, dom = max(cands)
                 k = kernels[dom]
-                per_launch_ms = k["ms_per_step"] / max(k["launches_per_step"], 1)
-                achieved = k["alg_GB"] / k["launches_per_step"] / (per_launch_ms / 1e3) if per_launch_ms > 0 else 0.0
+                lps = max(k["launches_per_step"], 1)
+                alg_launch = k["alg_GB"] * 1e9 / lps
+                per_launch_ms = k["ms_per_step"] / lps
+                achieved = alg_launch / 1e9 / (per_launch_ms / 1e3) if per_launch_ms > 0 else 0.0
                 standalone = {"avg_launch_ms": round(per_launch_ms, 4), "achieved": round(achieved, 1),
                               "frac": round(achieved / HBM_PEAK_GBS, 4)}
                 if dom in prof_timed and prof_timed[dom][1] > 0:      # the same kernel as it ran inside the timed region
                     t_ms, t_n = prof_timed[dom]
                     per_launch_ms = t_ms / t_n
-                    achieved = k["alg_GB"] / k["launches_per_step"] / (per_launch_ms / 1e3) if per_launch_ms > 0 else 0.0
+                    achieved = alg_launch / 1e9 / (per_launch_ms / 1e3) if per_launch_ms > 0 else 0.0
                 tr = traffic.get(dom)
-                roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                roofline = {"bound": "valu_fp64" if dom == "assess_all" else "hbm", "kernel": dom,
+                            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                            "traffic": (tr / k["launches_per_step"]) if tr is not None else None,
+                            # HBM bytes per launch from the PMC counters, reads doubled as the microarchitecture guide
+                            # prescribes for gfx950 (traffic_calibrated: reads scaled by the factor measured on the pure copy)
+                            "traffic": (tr["total_2x"] / max(tr["launches_per_step"], 1)) if tr else None,
+                            "traffic_calibrated": (tr["total"] / max(tr["launches_per_step"], 1)) if tr else None,
                             "traffic_source": traffic.get("_source"),
-                            "traffic_note": traffic.get("_note"),
+                            "traffic_build_digest": traffic.get("_build_digest"),
                             "avg_launch_ms": round(per_launch_ms, 4),
-                            "alg_bytes_per_launch": k["alg_GB"] / k["launches_per_step"] * 1e9,
+                            "alg_bytes_per_launch": alg_launch,
                             "measured_in": "timed region (this kernel shares the GPU with the next image's tile stage and "
                                            "pyramids there)" if dom in prof_timed else "separate sequential pass",
                             "standalone": standalone}
                 if dom == "assess_all":
-                    roofline["note"] = ("fp64-VALU-bound: the reference's SSIM is float64; ~126 fp64 ops per pixel put its "
-                                        "floor near 0.65 ms at 200 MP, above its 0.2 ms HBM time")
+                    # the kernel that dominates is not HBM-bound: its own roof is fp64 VALU issue (the reference's SSIM is
+                    # float64).  floor = pixels x (fp64-rate instr x 4 + fp32-rate instr x 2 cycles per wave of 64) / SIMDs / clock
+                    px = geo.canvas_pixels * share
+                    cyc = ASSESS_FP64_INSTR_PER_PX * 4 + ASSESS_FP32_INSTR_PER_PX * 2
+                    floor_ms = 1e3 * (px / 64.0) * cyc / GPU_SIMDS / GPU_CLOCK_HZ
+                    roofline["valu"] = {"floor_ms": round(floor_ms, 4), "frac": round(floor_ms / per_launch_ms, 4) if per_launch_ms > 0 else None,
+                                        "frac_standalone": round(floor_ms / standalone["avg_launch_ms"], 4) if standalone["avg_launch_ms"] > 0 else None,
+                                        "model": f"{ASSESS_FP64_INSTR_PER_PX} fp64-rate (4 cycles / wave) + {ASSESS_FP32_INSTR_PER_PX} fp32-rate "
+                                                 f"(2 cycles / wave) VALU instructions per pixel, {GPU_SIMDS} SIMDs at {GPU_CLOCK_HZ / 1e9:.1f} GHz; "
+                                                 "column halo of the march not counted"}
+                    roofline["note"] = ("fp64-VALU-bound: `frac` is the HBM fraction the contract asks for, `valu.frac` the fraction "
+                                        "of the kernel's own (instruction-issue) roof")
+            blend_ms = sum(v["ms_per_step"] for kk, v in kernels.items() if kk in ("weight_down",) + BLEND_FAMILIES)
+            roofline_blend = None
+            if blend_ms > 0:
+                bt = [traffic.get(kk) for kk in BLEND_FAMILIES]
+                roofline_blend = {"bound": "hbm", "kernels": [kk for kk in BLEND_FAMILIES if kk in kernels],
+                                  "achieved": round(blend_alg / 1e9 / (blend_ms / 1e3), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(blend_alg / 1e9 / (blend_ms / 1e3) / HBM_PEAK_GBS, 4),
+                                  "alg_bytes": blend_alg, "ms": round(blend_ms, 4),
+                                  "traffic": sum(t["total_2x"] for t in bt) if all(bt) else None,
+                                  "traffic_calibrated": sum(t["total"] for t in bt) if all(bt) else None,
+                                  "traffic_source": traffic.get("_source"),
+                                  "timed_in": "separate sequential pass (standalone kernels, one image at a time)",
+                                  "note": "the Laplacian blend of one image (pyramid down chain, collapse, canvas gather): "
+                                          "north_star's >= 60 % target is on this figure; alg_bytes is this design's (gather) "
+                                          "byte model, smaller than SURVEY 8(d)'s scatter model"}
             gpu_ms = sum(v["ms_per_step"] for v in kernels.values())
-            blend_ms = sum(v["ms_per_step"] for kk, v in kernels.items()
-                           if kk in ("weight_down", "down_l0", "down_l1p", "up_level", "final_gather"))
             total_alg = sum(alg[kk] for kk in kernels if kk in alg)
             out.update({
                 "pcie": pcie,
@@ -411,6 +502,8 @@ def run_workload(args, workload: str, steps: int, warmup: int, detailed: bool, d
                                "note": "SR stand-in = cv2.INTER_CUBIC upscale of the 720p source on the GPU (sr_resize_cubic_u8), "
                                        "outside the timed region and outside the roofline"},
                 "roofline": roofline,
+                "roofline_blend": roofline_blend,
+                "latency_ms_single_image": latency_single,
                 "kernels": kernels,
                 "blend": {"ms_per_step": round(blend_ms, 4),
                           "alg_GB": round(blend_alg / 1e9, 3),
@@ -423,14 +516,17 @@ def run_workload(args, workload: str, steps: int, warmup: int, detailed: bool, d
                             round(alg["_survey_blend_model"] / 1e9 / (blend_ms / 1e3), 1),
                             "whole_step_alg_GBps": None if ms_per_step <= 0 else round(total_alg / 1e9 / (ms_per_step / 1e3), 1)},
             })
-            if world == 1 and not args.no_cpu_baseline:
-                # the k-d workloads time the grid geometry of the same canvas (same pixels, same kernels on the CPU side)
-                out["cpu_baseline"] = cpu_baseline(src_ref, dp.workload_geometry(workload.replace("-kd", "")))
-            else:
-                out["cpu_baseline"] = None
     pipe.close()
     del pipe, reference, image, t_src
     torch.cuda.empty_cache()
+    if out is not None and detailed:
+        out["cpu_baseline"] = out["parity"] = None
+        if world == 1 and not args.no_cpu_baseline:
+            # the k-d workloads time the grid geometry of the same canvas (same pixels, same kernels on the CPU side)
+            geo_grid = dp.workload_geometry(workload.replace("-kd", ""))
+            sample, out["cpu_baseline"] = cpu_baseline(src_ref, geo_grid)
+            out["parity"] = parity_vs_oracle(sample, geo_grid, local_rank)   # the oracle as checker, never in a timed region
+            del sample
     return out
 
 

@@ -208,7 +208,10 @@ SR_API int sr_comm_exchange_tile_rows(sr_ctx *ctx, sr_comm *comm, const sr_tile_
 /* SURVEY 8(b)'s sr_laplacian_blend_sharded: sr_comm_exchange_tile_rows followed, on the same stream, by sr_laplacian_blend of
  * this rank's rows -- plan = sr_blend_plan_create(..., rows[2 rank], rows[2 rank + 1]) of the exchange plan, the received
  * windows addressed through virtual base pointers.  (A host that wants the exchange of image i + 1 under the blend of image
- * i issues the two calls itself on two streams, as device_pipeline.py does.) */
+ * i issues the two calls itself on two streams, as device_pipeline.py does.)  `plan` must have been created on `ctx` (one
+ * stream orders the receive before the blend) for the same n tiles and cn channels: SR_ERR_INVALID_ARG / SR_ERR_SHAPE
+ * otherwise; the tile arguments are checked by sr_sharded_tile_bases before anything is posted.  If a post inside the RCCL
+ * group fails (SR_ERR_COMM) the batch is partial and the communicator must be destroyed: further calls on it fail. */
 SR_API int sr_laplacian_blend_sharded(sr_ctx *ctx, sr_comm *comm, sr_blend_plan *plan, const sr_tile_rect *h_tiles, int n, int cn,
                                       const int *h_need, const int *h_owner, const void *const *d_owned,
                                       const int64_t *strides, void *const *d_recv, uint8_t *d_canvas, int64_t canvas_stride);
@@ -219,6 +222,13 @@ SR_API int sr_exchange_xfers(const sr_tile_rect *h_tiles, int n, int cn, int wor
                              const int *h_owner, const void *const *d_owned, const int64_t *owned_stride,
                              void *const *d_recv, sr_xfer *sends, int cap_send, int *n_send, sr_xfer *recvs, int cap_recv,
                              int *n_recv);
+/* host only: the per-tile base pointers rank `rank` hands to its strip blend -- an owned tile as it is, a received row window
+ * moved up to its (virtual) row 0 (d_recv[t] - r0 * w * cn).  Validates what sr_laplacian_blend_sharded relies on: owners
+ * inside the world, rows inside the tile, a dense stride (w * cn) for every tile that is received (SR_ERR_SHAPE otherwise),
+ * a buffer for every window.  h_base[n] receives the pointers (NULL for tiles this strip does not read). */
+SR_API int sr_sharded_tile_bases(const sr_tile_rect *h_tiles, int n, int cn, int world, int rank, const int *h_need,
+                                 const int *h_owner, const void *const *d_owned, const int64_t *strides,
+                                 void *const *d_recv, void **h_base);
 SR_API int sr_comm_allreduce_f64(sr_ctx *ctx, sr_comm *comm, double *d_buf, int count);
 /* tile-local rows [*r0, *r1) of tile t that the plan reads (empty if r0 >= r1): what a strip
  * owner must hold / receive for that tile. */

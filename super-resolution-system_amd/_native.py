@@ -110,6 +110,8 @@ SIGNATURES = {
     "sr_comm_allreduce_f64": (_i, [_vp, _vp, _vp, _i]),
     "sr_laplacian_blend_sharded": (_i, [_vp, _vp, _vp, C.POINTER(TileRect), _i, _i, _pi, _pi, C.POINTER(_vp), C.POINTER(_i64),
                                         C.POINTER(_vp), _vp, _i64]),
+    "sr_sharded_tile_bases": (_i, [C.POINTER(TileRect), _i, _i, _i, _i, _pi, _pi, C.POINTER(_vp), C.POINTER(_i64), C.POINTER(_vp),
+                                   C.POINTER(_vp)]),
     "sr_exchange_xfers": (_i, [C.POINTER(TileRect), _i, _i, _i, _i, _pi, _pi, C.POINTER(_vp), C.POINTER(_i64), C.POINTER(_vp),
                                C.POINTER(Xfer), _i, _pi, C.POINTER(Xfer), _i, _pi]),
     "sr_strip_bounds": (_i, [C.POINTER(TileRect), _i, _i, _i, _i, _i, _pi]),
@@ -704,6 +706,15 @@ def exchange_xfers(rects_xywh, cn: int, world: int, rank: int, need, owners, own
             [(recvs[i].peer, recvs[i].d_ptr or 0, recvs[i].bytes) for i in range(nr.value)])
 
 
+def sharded_tile_bases(rects_xywh, cn: int, world: int, rank: int, need, owners, owned_ptrs, strides, recv_ptrs) -> List[int]:
+    """Host-only (sr_sharded_tile_bases): the per-tile base pointers rank `rank` hands to its strip blend (0 for tiles its
+    strip does not read); validates owners, rows, dense strides of received tiles and receive buffers."""
+    n, rects, flat, own, dp, st, rp = _xfer_args(rects_xywh, world, need, owners, owned_ptrs, strides, recv_ptrs)
+    base = (_vp * n)()
+    check(load().sr_sharded_tile_bases(rects, n, int(cn), int(world), int(rank), flat, own, dp, st, rp, base))
+    return [int(b or 0) for b in base]
+
+
 class Comm:
     """RCCL communicator of the C ABI (sr_comm_*): one process per GPU, transfers on the context's stream."""
 
@@ -727,6 +738,14 @@ class Comm:
         are device pointers or 0."""
         n, rects, flat, own, dp, st, rp = _xfer_args(rects_xywh, self.world, need, owners, owned_ptrs, owned_strides, recv_ptrs)
         check(load().sr_comm_exchange_tile_rows(self.ctx.handle, self.h, rects, n, int(cn), flat, own, dp, st, rp))
+
+    def blend_sharded(self, plan: "BlendPlan", rects_xywh, cn: int, need, owners, owned_ptrs, strides, recv_ptrs, d_canvas: int,
+                      canvas_stride: int, ctx: Optional["Context"] = None):
+        """sr_laplacian_blend_sharded: the row exchange and this rank's strip blend on one stream (plan made on the same
+        context, for the same tiles)."""
+        n, rects, flat, own, dp, st, rp = _xfer_args(rects_xywh, self.world, need, owners, owned_ptrs, strides, recv_ptrs)
+        check(load().sr_laplacian_blend_sharded((ctx or self.ctx).handle, self.h, plan.handle, rects, n, int(cn), flat, own, dp, st, rp,
+                                                _vp(int(d_canvas)), int(canvas_stride)))
 
     def allreduce_f64(self, d_ptr: int, count: int):
         check(load().sr_comm_allreduce_f64(self.ctx.handle, self.h, _vp(int(d_ptr)), int(count)))

@@ -105,6 +105,7 @@ struct sr_comm {
     ncclComm_t comm = nullptr;
     int world = 1, rank = 0;
     bool own = false;
+    bool broken = false;    // a post inside a group failed: nothing further is enqueued on this communicator
 };
 
 extern "C" {
@@ -191,6 +192,7 @@ int sr_comm_exchange(sr_ctx *ctx, sr_comm *comm, const sr_xfer *sends, int n_sen
                 return sr_set_error(SR_ERR_INVALID_ARG, "sr_comm_exchange: %s %d: peer %d of %d, %zu bytes at %p", pass ? "recv" : "send",
                                     i, x[i].peer, comm->world, (size_t)x[i].bytes, x[i].d_ptr);
     }
+    if (comm->broken) return sr_set_error(SR_ERR_COMM, "sr_comm_exchange: an earlier batch on this communicator failed; destroy it");
     CTX_ENTER(ctx);
     ProfScope prof(ctx, "comm_exchange");
     // one group: inside it the transfers of a pair match whatever their posting order, and two strips that send to
@@ -201,8 +203,14 @@ int sr_comm_exchange(sr_ctx *ctx, sr_comm *comm, const sr_xfer *sends, int n_sen
         if (sends[i].bytes) first = g_api.Send(sends[i].d_ptr, (size_t)sends[i].bytes, ncclUint8, sends[i].peer, comm->comm, ctx->stream);
     for (int i = 0; i < n_recv && first == ncclSuccess; ++i)
         if (recvs[i].bytes) first = g_api.Recv(recvs[i].d_ptr, (size_t)recvs[i].bytes, ncclUint8, recvs[i].peer, comm->comm, ctx->stream);
+    // A group must be closed; after a failed post the batch it launches is partial (peers will wait on the transfers that
+    // were never posted) and the communicator is unusable: the caller must destroy it (documented in sr_hip.h).
     ncclResult_t end = g_api.GroupEnd();
-    if (first != ncclSuccess) return sr_set_error(SR_ERR_COMM, "sr_comm_exchange: ncclSend/ncclRecv: %s", g_api.GetErrorString(first));
+    if (first != ncclSuccess) {
+        comm->broken = true;
+        return sr_set_error(SR_ERR_COMM, "sr_comm_exchange: ncclSend/ncclRecv: %s (partial batch; the communicator must be destroyed)",
+                            g_api.GetErrorString(first));
+    }
     if (end != ncclSuccess) return sr_set_error(SR_ERR_COMM, "sr_comm_exchange: ncclGroupEnd: %s", g_api.GetErrorString(end));
     return SR_OK;
 }
@@ -225,15 +233,25 @@ int sr_laplacian_blend_sharded(sr_ctx *ctx, sr_comm *comm, sr_blend_plan *plan, 
 {
     if (!comm || !plan || !h_tiles || !h_need || !h_owner || !d_owned || !strides || !d_recv || n < 1)
         return sr_set_error(SR_ERR_INVALID_ARG, "sr_laplacian_blend_sharded: bad arguments");
-    int rc = sr_comm_exchange_tile_rows(ctx, comm, h_tiles, n, cn, h_need, h_owner, d_owned, strides, d_recv);
-    if (rc) return rc;
-    // tile base pointers as the blend wants them: an owned tile as it is, a received window moved up to its (virtual) row 0
+    // The exchange is enqueued on ctx's stream and the blend on the plan's: they must be the same context, or the blend
+    // could read received rows before RCCL has written them.  The plan indexes n tiles of cn channels: the caller's must
+    // be those.
+    sr_ctx *plan_ctx = nullptr;
+    int plan_n = 0, plan_cn = 0;
+    if (!plan_describe(plan, &plan_ctx, &plan_n, &plan_cn))
+        return sr_set_error(SR_ERR_INVALID_ARG, "sr_laplacian_blend_sharded: null or destroyed plan");
+    if (plan_ctx != ctx)
+        return sr_set_error(SR_ERR_INVALID_ARG, "sr_laplacian_blend_sharded: the plan belongs to another context (the exchange "
+                                                "and the blend must share one stream)");
+    if (n != plan_n || cn != plan_cn)
+        return sr_set_error(SR_ERR_SHAPE, "sr_laplacian_blend_sharded: %d tiles x %d channels given, the plan has %d x %d", n, cn,
+                            plan_n, plan_cn);
+    // tile base pointers as the blend wants them (validated on the host before anything is posted)
     std::vector<void *> base((size_t)n, nullptr);
-    for (int t = 0; t < n; ++t) {
-        const int r0 = h_need[((size_t)comm->rank * n + t) * 2], r1 = h_need[((size_t)comm->rank * n + t) * 2 + 1];
-        if (h_owner[t] == comm->rank) base[(size_t)t] = (void *)d_owned[t];
-        else if (r0 < r1) base[(size_t)t] = (char *)d_recv[t] - (int64_t)r0 * strides[t];
-    }
+    int rc = sr_sharded_tile_bases(h_tiles, n, cn, comm->world, comm->rank, h_need, h_owner, d_owned, strides, d_recv, base.data());
+    if (rc) return rc;
+    rc = sr_comm_exchange_tile_rows(ctx, comm, h_tiles, n, cn, h_need, h_owner, d_owned, strides, d_recv);
+    if (rc) return rc;
     // same stream as the exchange: the blend starts when the rows have arrived
     return sr_laplacian_blend(plan, SR_U8, base.data(), strides, d_canvas, canvas_stride, nullptr);
 }

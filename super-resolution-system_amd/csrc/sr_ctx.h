@@ -63,6 +63,10 @@ hipError_t upload_if_changed(sr_ctx *c, void *d_dst, const void *h_src, size_t b
 // Same with a table that owns (and grows) its device buffer.
 hipError_t upload_cached(sr_ctx *c, CachedTable &t, const void *h_src, size_t bytes);
 bool ctx_is_live(const sr_ctx *c);
+// What a blend plan was made for (sr_comm.cpp cross-checks the arguments of the sharded blend); false when the plan is
+// null or destroyed.
+struct sr_blend_plan;
+bool plan_describe(const sr_blend_plan *p, sr_ctx **ctx, int *n, int *cn);
 int ctx_scratch(sr_ctx *c, size_t bytes, void **out);
 hipEvent_t prof_event(sr_ctx *c);
 int check_launch(const char *what);

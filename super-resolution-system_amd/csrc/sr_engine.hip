@@ -2451,6 +2451,15 @@ struct sr_blend_plan {
 
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+bool plan_describe(const sr_blend_plan *p, sr_ctx **ctx, int *n, int *cn)
+{
+    if (!plan_is_live(p)) return false;
+    if (ctx) *ctx = p->ctx;
+    if (n) *n = p->n;
+    if (cn) *cn = p->cn;
+    return true;
+}
+
 extern "C" {
 
 int sr_device_count(int *count)

@@ -351,6 +351,40 @@ int sr_exchange_xfers(const sr_tile_rect *h_tiles, int n, int cn, int world, int
     return SR_OK;
 }
 
+// Tile base pointers of one rank as the strip blend wants them (host only; nothing is dereferenced): an owned tile as it
+// is, a received row window moved up to its (virtual) row 0.  A receive buffer is dense -- w * cn bytes per row is what
+// sr_exchange_xfers posts -- so that is the only stride a non-owned tile may carry.
+int sr_sharded_tile_bases(const sr_tile_rect *h_tiles, int n, int cn, int world, int me, const int *h_need, const int *h_owner,
+                          const void *const *d_owned, const int64_t *strides, void *const *d_recv, void **h_base)
+{
+    if (!h_tiles || !h_need || !h_owner || !d_owned || !strides || !d_recv || !h_base || n < 1 || cn < 1 || world < 1 || me < 0 ||
+        me >= world)
+        return sr_set_error(SR_ERR_INVALID_ARG, "sr_sharded_tile_bases: bad arguments");
+    for (int t = 0; t < n; ++t) {
+        const int r0 = h_need[((size_t)me * n + t) * 2], r1 = h_need[((size_t)me * n + t) * 2 + 1];
+        h_base[t] = nullptr;
+        if (h_owner[t] < 0 || h_owner[t] >= world)
+            return sr_set_error(SR_ERR_INVALID_ARG, "sr_sharded_tile_bases: tile %d owner %d of %d ranks", t, h_owner[t], world);
+        if (r0 >= r1) continue;                                  // this strip does not read the tile
+        if (r0 < 0 || r1 > h_tiles[t].h)
+            return sr_set_error(SR_ERR_INVALID_ARG, "sr_sharded_tile_bases: tile %d rows [%d, %d) of %d", t, r0, r1, h_tiles[t].h);
+        const int64_t dense = (int64_t)h_tiles[t].w * cn;
+        if (h_owner[t] == me) {
+            if (!d_owned[t] || strides[t] < dense)
+                return sr_set_error(SR_ERR_INVALID_ARG, "sr_sharded_tile_bases: owned tile %d: pointer %p, stride %lld < %lld", t, d_owned[t],
+                                    (long long)strides[t], (long long)dense);
+            h_base[t] = (void *)d_owned[t];
+        } else {
+            if (strides[t] != dense)
+                return sr_set_error(SR_ERR_SHAPE, "sr_sharded_tile_bases: tile %d is received into a dense buffer (%lld bytes per row) but "
+                                                  "strides[%d] = %lld", t, (long long)dense, t, (long long)strides[t]);
+            if (!d_recv[t])
+                return sr_set_error(SR_ERR_INVALID_ARG, "sr_sharded_tile_bases: no receive buffer for rows [%d, %d) of tile %d", r0, r1, t);
+            h_base[t] = (char *)d_recv[t] - (int64_t)r0 * dense;
+        }
+    }
+    return SR_OK;
+}
 
 double sr_psnr_from_sse(uint64_t sse, uint64_t count, double data_range)
 {

@@ -114,3 +114,82 @@ def test_c_host_example(ctx, tmp_path):
         h = ((h ^ v) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
     assert got["strip_fnv1a"] == f"{h:016x}"
     assert want[0] > 0 and 0.0 < want[2] / (side * side) < 1.0
+
+
+def test_sharded_blend_rejects_mismatched_arguments(ctx, rng):
+    """sr_laplacian_blend_sharded cross-checks its handles before anything is posted: a plan made on another context (the
+    exchange and the blend would run on different streams), a tile count or channel count that is not the plan's, a
+    destroyed plan.  (Stride / owner / buffer checks of received tiles need world > 1: tests/test_planner.py drives them
+    through the host-only sr_sharded_tile_bases.)  The well-formed call equals the plain strip blend."""
+    import _native
+    import device_pipeline as dp
+    geo = dp.grid_geometry(tile_w=200, tile_h=160, rows=2, cols=2, ov_x=40)
+    n, cn = len(geo.rects), geo.cn
+    xp = dp.make_exchange_plan(geo, 1)
+    comm = _native.Comm(ctx, _native.comm_unique_id(), 1, 0)
+    other = _native.Context(0)
+    tiles = [ctx.upload(rng.integers(0, 256, (h, w * cn), dtype=np.uint8)) for (_, _, w, h) in geo.rects]
+    canvas, canvas2 = ctx.alloc(geo.canvas_h * geo.canvas_w * cn), ctx.alloc(geo.canvas_h * geo.canvas_w * cn)
+    ptrs, strides = [t.ptr for t in tiles], [w * cn for (_, _, w, _) in geo.rects]
+    plan = _native.BlendPlan(ctx, geo.rects, cn, geo.canvas_h, geo.canvas_w, geo.levels, geo.weight_type)
+    foreign = _native.BlendPlan(other, geo.rects, cn, geo.canvas_h, geo.canvas_w, geo.levels, geo.weight_type)
+    try:
+        args = (geo.rects, cn, xp.need, xp.owners, ptrs, strides, [0] * n, canvas.ptr, geo.canvas_w * cn)
+        comm.blend_sharded(plan, *args)
+        plan.blend(ptrs, strides, canvas2.ptr, geo.canvas_w * cn)
+        ctx.sync()
+        size = (geo.canvas_h * geo.canvas_w * cn,)
+        assert np.array_equal(ctx.download(canvas.ptr, size, np.uint8), ctx.download(canvas2.ptr, size, np.uint8))
+        with pytest.raises(ValueError, match="another context"):
+            comm.blend_sharded(foreign, *args)
+        with pytest.raises(_native.SrShapeError):                                   # fewer tiles than the plan indexes
+            comm.blend_sharded(plan, geo.rects[:3], cn, [xp.need[0][:3]], xp.owners[:3], ptrs[:3], strides[:3], [0] * 3,
+                               canvas.ptr, geo.canvas_w * cn)
+        with pytest.raises(_native.SrShapeError):                                   # channel count
+            comm.blend_sharded(plan, geo.rects, 1, xp.need, xp.owners, ptrs, strides, [0] * n, canvas.ptr, geo.canvas_w * cn)
+        foreign.close()
+        with pytest.raises(ValueError, match="destroyed plan"):
+            comm.blend_sharded(foreign, *args)
+    finally:
+        plan.close()
+        foreign.close()
+        for b in tiles + [canvas, canvas2]:
+            b.free()
+        other.close()
+        comm.close()
+
+
+def test_one_rccl_and_one_rocm_smi_mapped(ctx):
+    """Regression guard for the round-2 exit abort (two copies of librocm_smi64's statics in one process): after the C ABI's
+    communicator AND torch.distributed's RCCL group have been initialised, exactly one librccl and at most one
+    librocm_smi64 are mapped into this process."""
+    import os
+    import re
+    import torch
+    import torch.distributed as dist
+    import _native
+    comm = _native.Comm(ctx, _native.comm_unique_id(), 1, 0)
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        t = torch.ones(4, device="cuda")
+        dist.all_reduce(t)
+        torch.cuda.synchronize()
+        libs = set()
+        with open("/proc/self/maps") as f:
+            for line in f:
+                m = re.search(r"(/\S*lib(rccl|rocm_smi64)[^/\s]*\.so[^/\s]*)", line)
+                if m:
+                    libs.add(os.path.realpath(m.group(1)))
+        rccl = sorted(p for p in libs if "librccl" in p)
+        smi = sorted(p for p in libs if "librocm_smi64" in p)
+        assert len(rccl) == 1, rccl
+        assert len(smi) <= 1, smi
+    finally:
+        if created:
+            dist.destroy_process_group()
+        comm.close()

@@ -98,3 +98,53 @@ def test_exchange_xfers_match_plan(world):
         recv[plan.recvs(0)[0][1]] = 0
         with pytest.raises((_native.SrNativeError, ValueError)):
             _native.exchange_xfers(geo.rects, geo.cn, world, 0, plan.need, plan.owners, owned, strides, recv)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_tile_bases(world):
+    """sr_sharded_tile_bases (host only; what sr_laplacian_blend_sharded hands to the strip blend): owned tiles keep their
+    pointer, received windows are moved up to their virtual row 0 with the DENSE stride, tiles the strip does not read are
+    NULL -- and every inconsistency the sharded blend would turn into a wild device read is refused on the host."""
+    geo = dp.workload_geometry("200MP")
+    plan = dp.make_exchange_plan(geo, world)
+    n = len(geo.rects)
+    strides = [w * geo.cn for (_, _, w, _) in geo.rects]
+    for rank in (0, world - 1):
+        owned = [(0x10000000 + t * 0x4000000) if plan.owners[t] == rank else 0 for t in range(n)]
+        need = plan.need[rank]
+        recv = [(0x7000000000 + t * 0x4000000) if (plan.owners[t] != rank and need[t][0] < need[t][1]) else 0 for t in range(n)]
+        base = _native.sharded_tile_bases(geo.rects, geo.cn, world, rank, plan.need, plan.owners, owned, strides, recv)
+        for t in range(n):
+            a, b = need[t]
+            if a >= b:
+                assert base[t] == 0
+            elif plan.owners[t] == rank:
+                assert base[t] == owned[t]
+            else:
+                assert base[t] == recv[t] - a * strides[t]
+        got = [t for t in range(n) if plan.owners[t] != rank and need[t][0] < need[t][1]]
+        assert got, "the 200 MP plan has remote tiles for every rank"
+        t = got[0]
+        for bad_stride in (0, strides[t] + 64, -strides[t]):       # stale / padded / nonsense stride of a RECEIVED tile
+            bad = list(strides)
+            bad[t] = bad_stride
+            with pytest.raises(_native.SrShapeError):
+                _native.sharded_tile_bases(geo.rects, geo.cn, world, rank, plan.need, plan.owners, owned, bad, recv)
+        no_buf = list(recv)
+        no_buf[t] = 0
+        with pytest.raises(ValueError):
+            _native.sharded_tile_bases(geo.rects, geo.cn, world, rank, plan.need, plan.owners, owned, strides, no_buf)
+        owners = list(plan.owners)
+        owners[t] = world                                          # owner outside the communicator
+        with pytest.raises(ValueError):
+            _native.sharded_tile_bases(geo.rects, geo.cn, world, rank, plan.need, owners, owned, strides, recv)
+        need_bad = [list(r) for r in plan.need]
+        need_bad[rank][t] = (need[t][0], geo.rects[t][3] + 1)      # rows beyond the tile
+        with pytest.raises(ValueError):
+            _native.sharded_tile_bases(geo.rects, geo.cn, world, rank, need_bad, plan.owners, owned, strides, recv)
+        mine = [t for t in range(n) if plan.owners[t] == rank and need[t][0] < need[t][1]]
+        if mine:
+            short = list(strides)
+            short[mine[0]] -= 1                                    # an owned tile whose rows overlap
+            with pytest.raises(ValueError):
+                _native.sharded_tile_bases(geo.rects, geo.cn, world, rank, plan.need, plan.owners, owned, short, recv)

@@ -1,11 +1,21 @@
 #!/usr/bin/env python3
-"""Turns gpurun_out/profiles_<tag>/ (tools/collect_profiles.sh) into the committed summaries:
-    profiles/<round>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary
-    profiles/<round>_traffic.json       per-kernel HBM bytes per launch from FETCH_SIZE / WRITE_SIZE
-    profiles/<round>_bench.json         the bench line of the same build
-FETCH_SIZE on gfx950 under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM): the read side is
-calibrated on k_tile_extract, a pure copy whose byte count is known exactly, and that factor is applied to all kernels.
-usage: tools/summarize_profiles.py <tag> <round-prefix>      e.g.  r01b  r01_b
+"""Turns ONE collection made by tools/collect_profiles.sh (gpurun_out/profiles_<tag>/) into the committed summaries:
+    profiles/<prefix>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (same command as the bench line)
+    profiles/<prefix>_traffic.json       per-kernel HBM bytes PER LAUNCH and per step from FETCH_SIZE / WRITE_SIZE
+    profiles/<prefix>_bench.json         the bench line of the same build (its roofline pointed at these counters)
+    profiles/<prefix>_bench_<wl>.json    the other workloads
+
+Rules (round-2 verdict, weak #3):
+  * only the run directory named in <collection>/run_id.txt is read -- gpurun MERGES gpurun_out/, so an older collection
+    under the same tag may still sit beside the new one; every counter CSV must come from one build (the bench line's
+    source digest is recorded);
+  * every kernel is divided by ITS OWN launch count (per launch) and by the number of steps the PMC command ran (per step),
+    never by another kernel's count;
+  * reads are reported twice: `2x` = FETCH_SIZE x 2 as MI355X_MICROARCH.md prescribes for gfx950, `calibrated` = FETCH_SIZE x
+    the factor measured on k_tile_extract (a pure copy whose byte count is known);
+  * the script FAILS when a bench kernel family's corrected traffic is below 0.9 x its algorithmic bytes (that can only be
+    a bookkeeping error).
+usage: tools/summarize_profiles.py <tag> <prefix>      e.g.  r03a  r03_a
 """
 import collections
 import csv
@@ -15,52 +25,103 @@ import os
 import shutil
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench as bench_mod  # noqa: E402
+
 tag, prefix = sys.argv[1], sys.argv[2]
 src = f"gpurun_out/profiles_{tag}"
+run_id = open(f"{src}/run_id.txt").read().strip()
+meta = json.load(open(f"{src}/{run_id}/meta.json"))
+run = f"{src}/{run_id}"
 os.makedirs("profiles", exist_ok=True)
-shutil.copy(f"{src}/kernel_stats.csv", f"profiles/{prefix}_kernel_stats.csv")
-bench = json.load(open(f"{src}/bench.json"))
-json.dump(bench, open(f"profiles/{prefix}_bench.json", "w"), indent=1)
+shutil.copy(f"{run}/kernel_stats.csv", f"profiles/{prefix}_kernel_stats.csv")
+bench = json.load(open(f"{run}/bench.json"))
+pmc_steps = meta["pmc_steps"] + meta["pmc_warmup"]              # every step of the PMC command launches every kernel
 
 
 def counter(name):
-    """-> kernel -> counter total per bench step (sum over the launches of the run / number of steps run)."""
+    """-> kernel -> list of per-launch counter values (this run only)."""
     agg = collections.defaultdict(list)
-    for f in glob.glob(f"{src}/pmc_{name}/*/*_counter_collection.csv"):
+    files = glob.glob(f"{run}/pmc_{name}/**/*_counter_collection.csv", recursive=True)
+    if not files:
+        sys.exit(f"no counter CSV for {name} under {run}")
+    for f in files:
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == name:
                 agg[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
-    steps = max(len(agg.get("k_tile_extract", [])), 1)            # one extract launch per step
-    return {k: sum(v) / steps for k, v in agg.items()}
+    return agg
 
 
 fetch, write = counter("FETCH_SIZE"), counter("WRITE_SIZE")
 tile_px, canvas_px = bench["config"]["tile_pixels"], bench["config"]["canvas_pixels"]
-known_read = 3.0 * tile_px                      # k_tile_extract reads exactly the tile pixels once
-cal = known_read / (fetch["k_tile_extract"] * 1024.0) if fetch.get("k_tile_extract") else 2.0
-out = {"unit": "bytes per bench step (all launches of the kernel)", "fetch_calibration_factor": cal,
-       "note": "read = FETCH_SIZE*1024*factor with the factor calibrated on k_tile_extract (a pure copy of known size), "
-               "read_2x = FETCH_SIZE*1024*2 (the guide's correction for 16-B-per-lane streams; an upper bound for the "
-               "12-byte and byte-aligned loads used here); write = WRITE_SIZE*1024; total uses the calibrated read, "
-               "total_2x the guide's",
+ext = fetch.get("k_tile_extract")
+if not ext:
+    sys.exit("k_tile_extract missing from the FETCH_SIZE pass")
+known_read = 3.0 * tile_px                      # k_tile_extract reads exactly the tile pixels once per launch
+cal = known_read / (sum(ext) / len(ext) * 1024.0)
+out = {"format": 2, "run_id": run_id, "build_digest": meta.get("build_digest"),
+       "pmc_command_steps": pmc_steps, "fetch_calibration_factor": cal,
+       "note": "per_launch = counter sum over the kernel's launches / its own launch count; per_step = sum / steps of the PMC "
+               "command; read_2x = FETCH_SIZE*1024*2 (MI355X_MICROARCH.md: gfx950 reports half the bytes of wide streaming "
+               "reads), read = FETCH_SIZE*1024*factor calibrated on k_tile_extract; write = WRITE_SIZE*1024",
        "kernels": {}}
 for k in sorted(set(fetch) | set(write)):
     if not k.startswith("k_"):
         continue
-    raw = fetch.get(k, 0.0) * 1024.0
-    rd, wr = raw * cal, write.get(k, 0.0) * 1024.0
-    out["kernels"][k] = {"read": rd, "read_2x": raw * 2.0, "write": wr, "total": rd + wr, "total_2x": raw * 2.0 + wr}
+    nf, nw = len(fetch.get(k, [])), len(write.get(k, []))
+    if nf and nw and nf != nw:
+        sys.exit(f"{k}: {nf} launches in the FETCH pass, {nw} in the WRITE pass -- not one build / one command")
+    n = max(nf, nw)
+    raw, wr = sum(fetch.get(k, [])) * 1024.0, sum(write.get(k, [])) * 1024.0
+    rec = {}
+    for label, div in (("per_launch", n), ("per_step", pmc_steps)):
+        rec[label] = {"read": raw * cal / div, "read_2x": raw * 2.0 / div, "write": wr / div,
+                      "total": (raw * cal + wr) / div, "total_2x": (raw * 2.0 + wr) / div}
+    rec["launches"] = n
+    rec["launches_per_step"] = n / pmc_steps
+    out["kernels"][k] = rec
+
+# consistency: corrected traffic of a bench family can not be below its algorithmic bytes
+geo = type("G", (), {"tile_pixels": tile_px, "canvas_pixels": canvas_px})
+alg = bench_mod.algorithmic_bytes(geo)
+fam_tot = collections.defaultdict(float)
+for k, rec in out["kernels"].items():
+    fam = bench_mod.family_of(k)
+    if fam:
+        fam_tot[fam] += rec["per_step"]["total_2x"]
+out["families"] = {}
+bad = []
+for fam, tot in sorted(fam_tot.items()):
+    ratio = tot / alg[fam]
+    out["families"][fam] = {"traffic_2x_per_step": tot, "alg_bytes_per_step": alg[fam], "ratio": ratio}
+    if ratio < 0.9:
+        bad.append(f"{fam}: {tot / 1e9:.3f} GB counted (2x-corrected) < 0.9 x {alg[fam] / 1e9:.3f} GB algorithmic")
 json.dump(out, open(f"profiles/{prefix}_traffic.json", "w"), indent=1)
-# the bench line of this collection was printed before this summary existed: point its roofline at these counters
+if bad:
+    sys.exit("traffic below algorithmic bytes -- bookkeeping error:\n  " + "\n  ".join(bad))
+
+# the bench line of this collection was printed before this summary existed: point its rooflines at these counters
 roof = bench.get("roofline") or {}
-if roof.get("kernel"):
-    sys.path.insert(0, ".")
-    import bench as bench_mod
-    names = bench_mod.ROCPROF_NAMES.get(roof["kernel"], [])
-    names = names if isinstance(names, list) else [names]
-    vals = [out["kernels"][n]["total"] for n in names if n in out["kernels"]]
-    if vals:
-        lps = bench["kernels"][roof["kernel"]]["launches_per_step"]
-        roof["traffic"], roof["traffic_source"] = sum(vals) / max(lps, 1), f"{prefix}_traffic.json"
-        json.dump(bench, open(f"profiles/{prefix}_bench.json", "w"), indent=1)
-print(json.dumps(out, indent=1)[:3000])
+fam = roof.get("kernel")
+if fam in fam_tot:
+    lps = sum(rec["launches_per_step"] for k, rec in out["kernels"].items() if bench_mod.family_of(k) == fam)
+    roof["traffic"] = fam_tot[fam] / max(lps, 1)
+    roof["traffic_calibrated"] = sum(rec["per_step"]["total"] for k, rec in out["kernels"].items()
+                                     if bench_mod.family_of(k) == fam) / max(lps, 1)
+    roof["traffic_source"], roof["traffic_build_digest"] = f"{prefix}_traffic.json", out["build_digest"]
+rb = bench.get("roofline_blend") or {}
+if rb and all(f in fam_tot for f in bench_mod.BLEND_FAMILIES):
+    rb["traffic"] = sum(fam_tot[f] for f in bench_mod.BLEND_FAMILIES)
+    rb["traffic_source"] = f"{prefix}_traffic.json"
+json.dump(bench, open(f"profiles/{prefix}_bench.json", "w"), indent=1)
+for f in glob.glob(f"{run}/bench_*.json"):
+    name = os.path.basename(f)
+    if name == "bench_under_trace.json" or os.path.getsize(f) == 0:
+        continue
+    shutil.copy(f, f"profiles/{prefix}_{name}")
+# cross-check: the trace's average duration of the dominant kernel vs the bench line's own HIP-event time
+for r in csv.DictReader(open(f"profiles/{prefix}_kernel_stats.csv")):
+    if bench_mod.family_of(r["Name"]) == fam:
+        print(f"[check] {fam}: rocprofv3 average {float(r['AverageNs']) / 1e6:.4f} ms over {r['Calls']} calls; bench line: "
+              f"{roof.get('avg_launch_ms')} ms in region, {roof.get('standalone', {}).get('avg_launch_ms')} ms standalone")
+print(json.dumps(out["families"], indent=1))
