@@ -190,26 +190,58 @@ def parity_vs_oracle(sample: dict, geo_full, device_index: int) -> dict:
             "oracle": "restated reference CPU path; its OpenCV-defined semantics are parity-unpinned (DESIGN.md 2)"}
 
 
-def _launch_ranks(n: int, argv) -> int:
+_STAGE_FILE = os.environ.get("SR_BENCH_STAGE_FILE")
+
+
+def _stage(name: str) -> None:
+    """Progress marker of one rank (N > 1 only): the launcher prints each rank's last completed stage when its deadline
+    passes, so a rank stuck in a collective is named instead of the run dying silently at the driver's limit."""
+    if _STAGE_FILE:
+        try:
+            with open(_STAGE_FILE, "a") as f:
+                f.write(f"{time.time():.3f} {name}\n")
+        except OSError:
+            pass
+
+
+def _launch_ranks(n: int, argv, deadline_s: float) -> int:
     """``python bench.py --gpus N`` without a launcher around it: start the N ranks as CHILD processes (one per GPU,
     env:// rendezvous on 127.0.0.1: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) before anything in this
     process has touched torch or HIP.  The children write straight to our stdout / stderr (rank 0 prints the JSON
-    line).  Returns the first non-zero child status (the other ranks are then stopped), else 0.  Never exec: a process
-    that has initialised the GPU must not be replaced -- and this one never initialises it."""
+    line).  Returns the first non-zero child status (the other ranks are then stopped), else 0; after ``deadline_s``
+    seconds the ranks still running are terminated, every rank's last completed stage is printed to stderr and the status
+    is 124.  Never exec: a process that has initialised the GPU must not be replaced -- and this one never initialises it;
+    the children are always fresh processes."""
     import socket
     import subprocess
+    import tempfile
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    stage_dir = tempfile.mkdtemp(prefix="sr_bench_stage_")
     procs = []
     for r in range(n):
         env = dict(os.environ)
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
-                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                    "SR_BENCH_STAGE_FILE": os.path.join(stage_dir, f"rank{r}")})
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
         env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+
+    def last_stages():
+        out = []
+        for r in range(n):
+            try:
+                lines = open(os.path.join(stage_dir, f"rank{r}")).read().split("\n")
+                lines = [ln for ln in lines if ln]
+                out.append(lines[-1].split(" ", 1)[1] if lines else "(nothing: not past the interpreter start)")
+            except OSError:
+                out.append("(no stage file)")
+        return out
+
     rc = 0
+    t_end = time.monotonic() + deadline_s
     alive = list(procs)
     while alive:
         for p in list(alive):
@@ -220,8 +252,27 @@ def _launch_ranks(n: int, argv) -> int:
             alive.remove(p)
             if code != 0 and rc == 0:
                 rc = code
+                print(f"bench.py: rank {procs.index(p)} exited with status {code}; stopping the others "
+                      f"(last stages: {last_stages()})", file=sys.stderr)
                 for q in alive:                              # a rank failed: the others would wait on it forever
                     q.terminate()
+        if alive and time.monotonic() > t_end:
+            stages = last_stages()
+            print(f"bench.py: deadline of {deadline_s:.0f} s passed with {len(alive)} of {n} ranks still running", file=sys.stderr)
+            for r, st in enumerate(stages):
+                state = "running" if procs[r] in alive else f"exited {procs[r].returncode}"
+                print(f"bench.py:   rank {r} [{state}] last completed stage: {st}", file=sys.stderr)
+            for q in alive:
+                q.terminate()
+            for q in alive:
+                try:
+                    q.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    q.kill()
+            rc = rc or 124
+            break
+    import shutil
+    shutil.rmtree(stage_dir, ignore_errors=True)
     return rc
 
 
@@ -234,6 +285,7 @@ def run_workload(args, workload: str, steps: int, warmup: int, detailed: bool, d
     world, rank, local_rank, backend, dev = dist_state
     geo = dp.workload_geometry(workload)
     H, W, cn = geo.canvas_h, geo.canvas_w, geo.cn
+    _stage(f"{workload}: start")
 
     # ---- inputs, resident in HBM before the timed region ----------------------------------------
     # reference = whole-image bicubic upscale of the synthetic 720p source; image (the "SR output" the
@@ -280,6 +332,7 @@ def run_workload(args, workload: str, steps: int, warmup: int, detailed: bool, d
     ctx.resize_cubic_u8(t_src[1].data_ptr(), sw * cn, sh, sw, cn, image.data_ptr(), W * cn, H, W)
     torch.cuda.synchronize()                     # the "end-to-end" column of SURVEY 8(d), never part of `value`
     sr_stub_ms = 1e3 * (time.perf_counter() - t_stub)
+    _stage(f"{workload}: inputs resident, pipeline built")
 
     def barrier():
         if world > 1:
@@ -322,6 +375,7 @@ def run_workload(args, workload: str, steps: int, warmup: int, detailed: bool, d
         prof_ctl.reset()
     run_steps(warmup)
     torch.cuda.synchronize()
+    _stage(f"{workload}: warm-up ({warmup} steps) done")
     if not no_prof and warmup > 0:
         warm = prof_ctl.get()
         if warm:
@@ -335,12 +389,15 @@ def run_workload(args, workload: str, steps: int, warmup: int, detailed: bool, d
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     barrier()
     torch.cuda.synchronize()
+    _stage(f"{workload}: barrier before the timed region passed")
     t0 = time.perf_counter()
     evs[0].record()
     run_steps(steps)
     torch.cuda.synchronize()
+    _stage(f"{workload}: timed steps enqueued and synchronised")
     barrier()
     elapsed = time.perf_counter() - t0
+    _stage(f"{workload}: timed region ({steps} steps) done")
     step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
     prof_timed = {} if no_prof else prof_ctl.get()               # the dominant kernel, inside the timed region
     prof, prof_steps = {}, max(1, min(steps, 5))
@@ -366,11 +423,27 @@ def run_workload(args, workload: str, steps: int, warmup: int, detailed: bool, d
         prof = prof_ctl.get()
     prof_ctl.enable(False)
 
+    _stage(f"{workload}: per-kernel pass done")
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     metrics = pipe.metrics()
+    # N > 1: what every rank exchanged and how long its grouped batch took, gathered on rank 0 so a scaling curve can be
+    # explained (strip bounds, bytes in / out per rank, tiles owned)
+    ranks_info = None
+    if world > 1 and not batch:
+        xp = pipe.xplan
+        mine = {"rank": rank, "strip_rows": list(pipe.strip), "blend_rows": [pipe.row_begin, pipe.row_end],
+                "tiles_owned": len(pipe.owned), "tiles_received": len(xp.recvs(rank)),
+                "exchange_bytes_in": xp.bytes_received(rank, geo),
+                "exchange_bytes_out": sum((b - a) * geo.rects[tt][2] * geo.cn for (_, tt, a, b) in xp.sends(rank)),
+                "exchange_wait_ms_per_step": round(1e3 * pipe.exchange_wait_s / max(pipe.exchange_waits, 1), 4),
+                "kernel_ms_per_step": {kk: round(ms / prof_steps, 4) for kk, (ms, _) in prof.items()}}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        ranks_info = gathered
+    _stage(f"{workload}: results gathered")
 
     pcie = None
     if world == 1 and detailed and not args.no_pcie:
@@ -421,6 +494,9 @@ def run_workload(args, workload: str, steps: int, warmup: int, detailed: bool, d
                         "max": round(step_ms[-1], 4), "clock": "HIP events on the main stream between consecutive images, rank 0"},
             "quality": {k: (v if np.isfinite(v) else str(v)) for k, v in metrics.items()},
         }
+        if ranks_info is not None:
+            out["ranks"] = ranks_info
+            out["config"]["strip_bounds"] = list(pipe.xplan.bounds)
         if lp_model is not None:
             out["config"]["workload"] += f" + LPIPS-{args.lpips} (synthetic weights, parity unpinned)"
             out["quality"][f"lpips_{args.lpips}_synthetic_weights"] = lp_value
@@ -551,13 +627,16 @@ def main() -> int:
                          "synthetic weights -- the pretrained ones are not available offline; timing does not depend on their "
                          "values); one GPU or batch mode only.  Not part of the default line.")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-kernel HIP-event timing")
+    ap.add_argument("--deadline-s", type=float, default=900.0,
+                    help="self-launched N > 1 runs: after this many seconds the launcher terminates the ranks still running, "
+                         "prints every rank's last completed stage and exits 124")
     args = ap.parse_args()
 
     if args.gpus < 1:
         print("bench.py: --gpus must be >= 1", file=sys.stderr)
         return 2
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        return _launch_ranks(args.gpus, sys.argv[1:])       # children only; this process never touches the GPU
+        return _launch_ranks(args.gpus, sys.argv[1:], args.deadline_s)   # children only; this process never touches the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -565,6 +644,9 @@ def main() -> int:
         print(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr)
         return 2
 
+    _stage("process started")
+    if str(rank) in os.environ.get("SR_BENCH_TEST_HANG_RANKS", "").split(","):   # tests: the launcher's deadline path
+        time.sleep(600)
     import torch
     import torch.distributed as dist
 
@@ -578,12 +660,14 @@ def main() -> int:
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    _stage("torch imported, GPU visible")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    _stage(f"process group ({backend}, world {world}) initialised")
     state = (world, rank, local_rank, backend, dev)
 
     out = run_workload(args, args.workload, args.steps, args.warmup, True, state)
@@ -600,8 +684,10 @@ def main() -> int:
     if rank == 0:
         out["sweep"] = sweep_out
         print(json.dumps(out), flush=True)
+    _stage("JSON line printed")
     if world > 1:
         dist.destroy_process_group()
+    _stage("done")
     return 0
 
 

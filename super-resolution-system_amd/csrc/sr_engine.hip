@@ -209,8 +209,12 @@ struct FinalDesc {
     long long g1, r1;      // float offsets of plane 0 of G_1 / R_1 in the arena
     const void *src;       // level-0 tile data (row 0, possibly virtual) and its row stride in bytes
     long long stride;
+    int H2, W2, P2, pad2;  // level 2 (the fused gather builds R_1 from it on the fly)
+    long long g2, r2;      // float offsets of plane 0 of G_2 / R_2
+    long long w1;          // float offset of the weight level 1 of the tile's class
+    long long pad3;
 };
-static_assert(sizeof(FinalDesc) == 80, "FinalDesc layout");
+static_assert(sizeof(FinalDesc) == 128, "FinalDesc layout");
 
 enum { SRC_U8 = 0, SRC_F32 = 1, SRC_PLANAR = 2, SRC_LUT = 3 };
 
@@ -1055,8 +1059,8 @@ __device__ __forceinline__ void div_shared(const float (&a)[CN], float w, float 
 }
 
 // normalise, clip, truncate and store the thread's pixels
-template <int CN>
-__device__ __forceinline__ void store_pixels(float (&acc)[2][4][CN], const float (&wacc)[2][4],
+template <int CN, int NR = 2>
+__device__ __forceinline__ void store_pixels(float (&acc)[NR][4][CN], const float (&wacc)[NR][4],
                                              unsigned char *__restrict__ canvas, long long cstride,
                                              float *__restrict__ canvas_f32, int cw, int x0, int y0, int nx, int ny)
 {
@@ -1065,18 +1069,18 @@ __device__ __forceinline__ void store_pixels(float (&acc)[2][4][CN], const float
     // feather zone, about half of a grid canvas) the divisions are skipped -- wave-uniform branch
     bool ones = true;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NR; ++j)
 #pragma unroll
         for (int k = 0; k < 4; ++k) ones = ones && (wacc[j][k] == 1.0f);
     if (__all(ones) == 0) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NR; ++j)
 #pragma unroll
             for (int k = 0; k < 4; ++k) div_shared<CN>(acc[j][k], __builtin_fmaxf(wacc[j][k], 1e-6f), acc[j][k]);
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        if (j >= ny) break;
+    for (int j = 0; j < NR; ++j) {
+        if (j >= ny) continue;
         unsigned ob[4 * CN];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -1221,6 +1225,445 @@ __global__ __launch_bounds__(256, SR_FINAL_WAVES) void k_final_fast(const FinalD
         else gather_tile_fast<DT, LAP, CN, true, true>(D, arena, luts, lx0, ly0, acc, wacc);
     }
     store_pixels<CN>(acc, wacc, canvas, cstride, canvas_f32, cw, x0, y0, nx, ny);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused final gather: levels 1 -> 0 -> canvas in ONE kernel.  R_1 (the collapsed level 1, reference
+// blending_module.py:340-363) is never written to memory: for every (block, covering tile) the block first builds the
+// window of R_1 it is about to sample -- each thread one 4 x 2 patch of one plane, exactly the expressions of
+// k_up_level_blk, from G_1 / W_1 / G_2 / R_2 -- into LDS together with the G_1 values it was made from, then every
+// thread gathers its 4 x 4 canvas pixels from those two LDS windows (blending_module.py:474-506: acc += R_0, wacc += W_0,
+// normalise, clip, truncate).  Against k_up_level_blk(level 1) + k_final_fast this drops the R_1 round trip
+// (12 B written + 12-18 B re-read per level-1 pixel), one launch, and the 3 x re-read of level-1 rows (a thread's 4 x 4
+// pixels share 4 level-1 rows; a block's window is fetched once, coalesced).  Same fp32 expression order everywhere:
+// bit-identical to the unfused path.
+//   regular block: 128 x 32 canvas pixels, 256 threads of 4 x 4 pixels; level-1 window <= 20 rows x 72 columns per plane
+//   edge blocks (cells with a border visit): 256 x 16 or 32 x 128 pixels, generic per-pixel border rules, same windows
+// ---------------------------------------------------------------------------------------------
+#define FU_BW 128
+#define FU_BH 32
+#define FU_LP 72              /* LDS pitch (floats) of a regular block's window: 18 patches of 4 columns */
+#define FU_PLANE 1632         /* floats per (array, plane) window: 20 x 72 regular, 12 x 136 / 68 x 24 edge shapes */
+
+// Is the thread's 4 x 4 rectangle an interior visit of tile D (all sixteen pixels inside, every level-1 tap of the fast
+// path inside the level and away from its borders)?  Regular and edge blocks evaluate this same test.
+__device__ __forceinline__ bool cell_is_interior(const FinalDesc &D, int lx0, int ly0, int nx, int ny)
+{
+    if (nx != 4 || ny != 4 || lx0 < 0 || ly0 < 0 || lx0 + 3 >= D.w || ly0 + 3 >= D.h) return false;
+    if (D.nl > 1) {
+        const int r0 = (ly0 - 1) >> 1, c0 = (lx0 - 1) >> 1;
+        return c0 >= 0 && c0 + 3 <= D.W1 - 1 && r0 >= 0 && r0 + 3 <= D.H1 - 1;
+    }
+    return true;
+}
+
+// The level-1 window (tile coordinates) a block of bw x bh canvas pixels at tile-local (lxa, lya) samples: rows R0 ..,
+// columns C0 .. in patches of 2 rows x 4 columns (R0 even, C0 a multiple of 4: the alignment k_up_level_blk's threads have).
+__device__ __forceinline__ bool fused_window(const FinalDesc &D, int lxa, int lya, int bw, int bh, int &R0, int &C0, int &npr, int &npc)
+{
+    const int c_lo = max((lxa - 1) >> 1, 0), r_lo = max((lya - 1) >> 1, 0);
+    const int c_hi = min(((lxa + bw - 5) >> 1) + 3, D.W1 - 1), r_hi = min(((lya + bh - 5) >> 1) + 3, D.H1 - 1);
+    C0 = c_lo & ~3;
+    R0 = r_lo & ~1;
+    if (c_hi < C0 || r_hi < R0) return false;
+    npc = (c_hi - C0) / 4 + 1;
+    npr = (r_hi - R0) / 2 + 1;
+    return true;
+}
+
+// Stage 1: R_1 and G_1 of the window into LDS.  One item = one 4 x 2 patch of one plane = up_level_thread's work.
+template <int CN>
+__device__ __forceinline__ void fused_stage1(const FinalDesc &D, const float *__restrict__ arena, float *lds, int R0, int C0,
+                                             int npr, int npc, int LP, int tid)
+{
+    const int per_plane = npr * npc, n_items = per_plane * CN;
+    const size_t plane1 = (size_t)D.H1 * D.P1, plane2 = (size_t)D.H2 * D.P2;
+    for (int item = tid; item < n_items; item += 256) {
+        const int c = item / per_plane, rem = item - c * per_plane;
+        const int pr = rem / npc, pc = rem - pr * npc;
+        const int px = C0 + 4 * pc, py = R0 + 2 * pr;
+        if (px >= D.W1 || py >= D.H1) continue;
+        const bool two = py + 1 < D.H1;
+        const float *g = arena + D.g1 + c * plane1 + (size_t)py * D.P1 + px;
+        const float *wr = arena + D.w1 + (size_t)py * D.P1 + px;
+        const f4_t g0v = ld_f4(g), g1v = two ? ld_f4(g + D.P1) : g0v;
+        const f4_t w0v = ld_f4(wr), w1v = two ? ld_f4(wr + D.P1) : w0v;
+        f4_t o0, o1;
+        if (D.nl == 2) {                         // level 1 is the top of this tile's pyramid: R = G * W
+            o0 = g0v * w0v;
+            o1 = g1v * w1v;
+        } else {
+            const int r0 = (py - 1) >> 1, c0 = (px - 1) >> 1;
+            const bool interior = c0 >= 0 && c0 + 3 <= D.W2 - 1 && r0 >= 0 && r0 + 2 <= D.H2 - 1;
+            const float *gs = arena + D.g2 + c * plane2, *rs = arena + D.r2 + c * plane2;
+            float ug[2][4], ur[2][4];
+            if (interior) {
+                up_block_interior<false, false>(gs, D.P2, r0, c0, ug);
+                up_block_interior<false, false>(rs, D.P2, r0, c0, ur);
+            } else {
+                up_block<false, false>(gs, D.H2, D.W2, D.P2, r0, c0, ug);
+                up_block<false, false>(rs, D.H2, D.W2, D.P2, r0, c0, ur);
+            }
+            o0.x = ur[0][0] + (g0v.x - ug[0][0]) * w0v.x;
+            o0.y = ur[0][1] + (g0v.y - ug[0][1]) * w0v.y;
+            o0.z = ur[0][2] + (g0v.z - ug[0][2]) * w0v.z;
+            o0.w = ur[0][3] + (g0v.w - ug[0][3]) * w0v.w;
+            o1.x = ur[1][0] + (g1v.x - ug[1][0]) * w1v.x;
+            o1.y = ur[1][1] + (g1v.y - ug[1][1]) * w1v.y;
+            o1.z = ur[1][2] + (g1v.z - ug[1][2]) * w1v.z;
+            o1.w = ur[1][3] + (g1v.w - ug[1][3]) * w1v.w;
+        }
+        float *dg = lds + c * FU_PLANE + (pr * 2) * LP + pc * 4;
+        float *dr = dg + CN * FU_PLANE;
+        st_f4(dg, g0v);
+        st_f4(dg + LP, g1v);
+        st_f4(dr, o0);
+        st_f4(dr + LP, o1);
+    }
+}
+
+// pyrUp of a 4-row x 4-column register neighbourhood -> the thread's 4 x 4 pixels (interior form; see up_regs for the
+// folded power-of-two factors).  Canvas rows j = 0..3 sample level-1 rows r0 .. r0 + 3.
+template <bool XO, bool YO>
+__device__ __forceinline__ void up_regs4(const f4_t (&q)[4], float (&u)[4][4])
+{
+    float h[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (!XO) {
+            h[r][0] = (q[r].x + q[r].y * 6.0f) + q[r].z;
+            h[r][1] = q[r].y + q[r].z;
+            h[r][2] = (q[r].y + q[r].z * 6.0f) + q[r].w;
+            h[r][3] = q[r].z + q[r].w;
+        } else {
+            h[r][0] = q[r].x + q[r].y;
+            h[r][1] = (q[r].x + q[r].y * 6.0f) + q[r].z;
+            h[r][2] = q[r].y + q[r].z;
+            h[r][3] = (q[r].y + q[r].z * 6.0f) + q[r].w;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool kodd = XO ? ((k & 1) == 0) : ((k & 1) == 1);
+        const float ce = kodd ? (1.0f / 16.0f) : (1.0f / 64.0f);
+        const float co = kodd ? (1.0f / 4.0f) : (1.0f / 16.0f);
+        if (!YO) {
+            u[0][k] = ((h[0][k] + h[1][k] * 6.0f) + h[2][k]) * ce;
+            u[1][k] = (h[1][k] + h[2][k]) * co;
+            u[2][k] = ((h[1][k] + h[2][k] * 6.0f) + h[3][k]) * ce;
+            u[3][k] = (h[2][k] + h[3][k]) * co;
+        } else {
+            u[0][k] = (h[0][k] + h[1][k]) * co;
+            u[1][k] = ((h[0][k] + h[1][k] * 6.0f) + h[2][k]) * ce;
+            u[2][k] = (h[1][k] + h[2][k]) * co;
+            u[3][k] = ((h[1][k] + h[2][k] * 6.0f) + h[3][k]) * ce;
+        }
+    }
+}
+
+// weights of an interior 4 x 4 visit (tile_weights_interior for four rows)
+__device__ __forceinline__ void cell_weights_interior(const FinalDesc &D, const float *__restrict__ luts, int lx0, int ly0,
+                                                      float (&w0)[4][4])
+{
+    const int dmin = min(min(ly0, D.h - 4 - ly0), min(lx0, D.w - 4 - lx0));
+    const float *lut = luts + D.lut_off;
+    if (dmin >= D.fw) {
+        const float wf = lut[D.fw];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w0[j][k] = wf;
+        return;
+    }
+    float fy[4], fx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fy[j] = lut[min(min(ly0 + j, D.h - 1 - ly0 - j), D.fw)];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) fx[k] = lut[min(min(lx0 + k, D.w - 1 - lx0 - k), D.fw)];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w0[j][k] = __builtin_fminf(fy[j], fx[k]);
+}
+
+// Stage 2, interior visit of a regular block: the thread's 4 x 4 pixels from the LDS windows (pitch FU_LP).  CODD: the
+// first tap column sits at an odd LDS column -- the taps are then read as three aligned 8-byte pairs instead of two.
+template <int DT, int CN, bool XO, bool YO, bool CODD>
+__device__ __forceinline__ void fused_gather_fast(const FinalDesc &D, const float *__restrict__ luts, const float *lds, int R0, int C0,
+                                                  int lx0, int ly0, float (&acc)[4][4][CN], float (&wacc)[4][4])
+{
+    const bool pyr = D.nl > 1;
+    float g0[4][4][CN];
+    u3_t qs[4];
+    constexpr bool LAZY = (DT == SRC_U8 && CN == 3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const char *srow = (const char *)D.src + (size_t)(ly0 + j) * D.stride;
+        if (LAZY) {
+            qs[j] = ld_u3_a1_g(srow + (size_t)lx0 * 3);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int c = 0; c < CN; ++c) {
+                    if (DT == SRC_U8) g0[j][k][c] = (float)((const unsigned char *)srow)[(lx0 + k) * CN + c];
+                    else g0[j][k][c] = ((const float *)srow)[(lx0 + k) * CN + c];
+                }
+        }
+    }
+    float w0[4][4];
+    cell_weights_interior(D, luts, lx0, ly0, w0);
+    auto px = [&](int j, int k, int c) -> float {
+        if (LAZY) {
+            const int b = 3 * k + c;
+            unsigned wd = (b >> 2) == 0 ? qs[j].x : ((b >> 2) == 1 ? qs[j].y : qs[j].z);
+            asm volatile("" : "+v"(wd));      // keeps the conversion at its use (see gather_tile_fast)
+            return (float)((wd >> (8 * (b & 3))) & 0xFFu);
+        }
+        return g0[j][k][c];
+    };
+    if (pyr) {
+        const int r0 = (ly0 - 1) >> 1, c0 = (lx0 - 1) >> 1;
+        const float *base = lds + (r0 - R0) * FU_LP + ((c0 - C0) & ~1);
+#pragma unroll
+        for (int c = 0; c < CN; ++c) {
+            float ug[4][4], ur[4][4];
+#pragma unroll
+            for (int arr = 0; arr < 2; ++arr) {
+                const float *p = base + (arr * CN + c) * FU_PLANE;
+                f4_t q[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const f2_t a = *(const f2_t *)(p + r * FU_LP), b = *(const f2_t *)(p + r * FU_LP + 2);
+                    if (!CODD) {
+                        q[r].x = a.x; q[r].y = a.y; q[r].z = b.x; q[r].w = b.y;
+                    } else {
+                        const f2_t d = *(const f2_t *)(p + r * FU_LP + 4);
+                        q[r].x = a.y; q[r].y = b.x; q[r].z = b.y; q[r].w = d.x;
+                    }
+                }
+                if (arr == 0) up_regs4<XO, YO>(q, ug);
+                else up_regs4<XO, YO>(q, ur);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float lap = px(j, k, c) - ug[j][k];
+                    const float wl = lap * w0[j][k];
+                    acc[j][k][c] += ur[j][k] + wl;
+                }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < CN; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[j][k][c] += px(j, k, c) * w0[j][k];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wacc[j][k] += w0[j][k];
+}
+
+// up_block over an LDS window: same clamps and border rules, the window's origin subtracted from the clamped indices
+template <bool XO, bool YO>
+__device__ __forceinline__ void up_block_win(const float *win, int hs, int ws, int LP, int R0, int C0, int r0, int c0, float (&u)[2][4])
+{
+    float v[3][4], h[3][4];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int ro = (min(max(r0 + r, 0), hs - 1) - R0) * LP - C0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[r][c] = win[ro + min(max(c0 + c, 0), ws - 1)];
+    }
+    up_rows4<XO>(v, ws, c0, h);
+    up_cols2<YO>(h, r0, u);
+}
+
+// any 4 x 2 visit from the LDS windows (gather_tile_generic with G_1 / R_1 in LDS)
+template <int DT, int CN, bool XO, bool YO>
+__device__ __forceinline__ void fused_gather_generic(const FinalDesc &D, const float *__restrict__ luts, const float *lds, int LP,
+                                                     int R0, int C0, int lx0, int ly0, unsigned valid, float (&acc)[2][4][CN],
+                                                     float (&wacc)[2][4])
+{
+    float w0[2][4];
+    tile_weights(D, luts, lx0, ly0, w0);
+    const int r0 = (ly0 - 1) >> 1, c0 = (lx0 - 1) >> 1;
+    const bool pyr = D.nl > 1;
+#pragma unroll
+    for (int c = 0; c < CN; ++c) {
+        float ug[2][4], ur[2][4];
+        if (pyr) {
+            up_block_win<XO, YO>(lds + c * FU_PLANE, D.H1, D.W1, LP, R0, C0, r0, c0, ug);
+            up_block_win<XO, YO>(lds + (CN + c) * FU_PLANE, D.H1, D.W1, LP, R0, C0, r0, c0, ur);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!(valid & (1u << (j * 4 + k)))) continue;
+                const char *srow = (const char *)D.src + (size_t)(ly0 + j) * D.stride;
+                float g0;
+                if (DT == SRC_U8) g0 = (float)((const unsigned char *)srow)[(lx0 + k) * CN + c];
+                else g0 = ((const float *)srow)[(lx0 + k) * CN + c];
+                float r;
+                if (pyr) {
+                    const float lap = g0 - ug[j][k];
+                    const float wl = lap * w0[j][k];
+                    r = ur[j][k] + wl;
+                } else {
+                    r = g0 * w0[j][k];
+                }
+                acc[j][k][c] += r;
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (valid & (1u << (j * 4 + k))) wacc[j][k] += w0[j][k];
+}
+
+// Edge blocks of the fused gather: the 4 x 4 cells with a border visit, as two 4 x 2 generic visits each.
+template <int DT, int CN>
+__device__ __forceinline__ void fused_edge_block(const FinalDesc *__restrict__ descs, const int4 *__restrict__ edge_blocks, int ebi,
+                                                 const int *__restrict__ cand_idx, const float *__restrict__ arena,
+                                                 const float *__restrict__ luts, float *lds, unsigned char *__restrict__ canvas,
+                                                 long long cstride, float *__restrict__ canvas_f32, int cw, int row_begin, int row_end)
+{
+    const int4 eb = edge_blocks[ebi];
+    const int c_begin = eb.w, c_end = edge_blocks[ebi + 1].w;
+    const int tid = threadIdx.x;
+    const int shape = eb.z;                                   // 0: 256 x 16 px (64 x 4 cells), 1: 32 x 128 px (8 x 32 cells)
+    const int bw = shape ? 32 : 256, bh = shape ? 128 : 16, LP = shape ? 24 : 136;
+    const int x0 = eb.x + (shape ? (tid & 7) : (tid & 63)) * 4;
+    const int y0 = eb.y + (shape ? (tid >> 3) : (tid >> 6)) * 4;
+    const bool inside = x0 < cw && y0 < row_end;
+    const int nx = min(4, cw - x0), ny = min(4, row_end - y0);
+    bool edge = false;
+    if (inside)
+        for (int i = c_begin; i < c_end; ++i) {
+            const FinalDesc &D = descs[cand_idx[i]];
+            const int lx0 = x0 - D.x, ly0 = y0 - D.y;
+            if (lx0 + nx <= 0 || ly0 + ny <= 0 || lx0 >= D.w || ly0 >= D.h) continue;
+            if (!cell_is_interior(D, lx0, ly0, nx, ny)) edge = true;
+        }
+    float acc[2][2][4][CN], wacc[2][2][4];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                wacc[hf][j][k] = 0.f;
+#pragma unroll
+                for (int c = 0; c < CN; ++c) acc[hf][j][k][c] = 0.f;
+            }
+    for (int i = c_begin; i < c_end; ++i) {
+        const FinalDesc &D = descs[cand_idx[i]];
+        int R0 = 0, C0 = 0, npr = 0, npc = 0;
+        const bool win = D.nl > 1 && fused_window(D, eb.x - D.x, eb.y - D.y, bw, bh, R0, C0, npr, npc);
+        if (win) fused_stage1<CN>(D, arena, lds, R0, C0, npr, npc, LP, tid);
+        __syncthreads();
+        const int lx0 = x0 - D.x, ly0 = y0 - D.y;
+        if (edge && !(lx0 + nx <= 0 || ly0 + ny <= 0 || lx0 >= D.w || ly0 >= D.h)) {
+            const bool xo = (D.x & 1) != 0;
+            const bool yo = ((row_begin - D.y) & 1) != 0;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int ly = ly0 + 2 * hf;
+                unsigned valid = 0;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (2 * hf + j < ny && k < nx && lx0 + k >= 0 && lx0 + k < D.w && ly + j >= 0 && ly + j < D.h)
+                            valid |= 1u << (j * 4 + k);
+                if (!valid) continue;
+                if (!xo && !yo) fused_gather_generic<DT, CN, false, false>(D, luts, lds, LP, R0, C0, lx0, ly, valid, acc[hf], wacc[hf]);
+                else if (xo && !yo) fused_gather_generic<DT, CN, true, false>(D, luts, lds, LP, R0, C0, lx0, ly, valid, acc[hf], wacc[hf]);
+                else if (!xo && yo) fused_gather_generic<DT, CN, false, true>(D, luts, lds, LP, R0, C0, lx0, ly, valid, acc[hf], wacc[hf]);
+                else fused_gather_generic<DT, CN, true, true>(D, luts, lds, LP, R0, C0, lx0, ly, valid, acc[hf], wacc[hf]);
+            }
+        }
+        __syncthreads();                                   // the next tile's stage 1 overwrites the windows
+    }
+    if (!edge) return;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+        if (2 * hf < ny) store_pixels<CN>(acc[hf], wacc[hf], canvas, cstride, canvas_f32, cw, x0, y0 + 2 * hf, nx, min(2, ny - 2 * hf));
+}
+
+template <int DT, int CN>
+__global__ __launch_bounds__(256, 3) void k_final_fused(const FinalDesc *__restrict__ descs, const int *__restrict__ cand_off,
+                                                        const int *__restrict__ cand_idx, const int4 *__restrict__ edge_blocks,
+                                                        const int *__restrict__ edge_cand, int n_edge, int nbx_r,
+                                                        const float *__restrict__ arena, const float *__restrict__ luts,
+                                                        unsigned char *__restrict__ canvas, long long cstride,
+                                                        float *__restrict__ canvas_f32, int cw, int row_begin, int row_end)
+{
+    __shared__ __attribute__((aligned(16))) float lds[2 * CN * FU_PLANE];
+    if ((int)blockIdx.x < n_edge) {
+        fused_edge_block<DT, CN>(descs, edge_blocks, (int)blockIdx.x, edge_cand, arena, luts, lds, canvas, cstride, canvas_f32, cw,
+                                 row_begin, row_end);
+        return;
+    }
+    const int blk = (int)blockIdx.x - n_edge;
+    const int by = blk / nbx_r, bx = blk - by * nbx_r;
+    const int c_begin = cand_off[blk], c_end = cand_off[blk + 1];
+    const int tid = threadIdx.x;
+    const int bx0 = bx * FU_BW, by0 = row_begin + by * FU_BH;
+    const int x0 = bx0 + (tid & 31) * 4, y0 = by0 + (tid >> 5) * 4;
+    const int nx = min(4, cw - x0), ny = min(4, row_end - y0);
+    // a cell with any border visit belongs to the edge blocks (which recompute every visit of it)
+    bool alive = x0 < cw && y0 < row_end;
+    for (int i = c_begin; i < c_end && alive; ++i) {
+        const FinalDesc &D = descs[cand_idx[i]];
+        const int lx0 = x0 - D.x, ly0 = y0 - D.y;
+        if (lx0 + nx <= 0 || ly0 + ny <= 0 || lx0 >= D.w || ly0 >= D.h) continue;
+        if (!cell_is_interior(D, lx0, ly0, nx, ny)) alive = false;
+    }
+    float acc[4][4][CN], wacc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            wacc[j][k] = 0.f;
+#pragma unroll
+            for (int c = 0; c < CN; ++c) acc[j][k][c] = 0.f;
+        }
+    for (int i = c_begin; i < c_end; ++i) {
+        const FinalDesc &D = descs[cand_idx[i]];
+        const int lxa = bx0 - D.x, lya = by0 - D.y;
+        int R0 = 0, C0 = 0, npr = 0, npc = 0;
+        const bool win = D.nl > 1 && fused_window(D, lxa, lya, FU_BW, FU_BH, R0, C0, npr, npc);    // block-uniform
+        if (win) fused_stage1<CN>(D, arena, lds, R0, C0, npr, npc, FU_LP, tid);
+        __syncthreads();
+        const int lx0 = x0 - D.x, ly0 = y0 - D.y;
+        if (alive && !(lx0 + 4 <= 0 || ly0 + 4 <= 0 || lx0 >= D.w || ly0 >= D.h)) {
+            const bool xo = (D.x & 1) != 0;                      // x0 is a multiple of 4
+            const bool yo = ((row_begin - D.y) & 1) != 0;        // y0 - row_begin is a multiple of 4
+            const bool codd = D.nl > 1 && ((((lxa - 1) >> 1) - C0) & 1) != 0;   // parity of every cell's first tap column (block-uniform)
+#define FU_CALL(XOV, YOV, CV) fused_gather_fast<DT, CN, XOV, YOV, CV>(D, luts, lds, R0, C0, lx0, ly0, acc, wacc)
+            if (!codd) {
+                if (!xo && !yo) FU_CALL(false, false, false);
+                else if (xo && !yo) FU_CALL(true, false, false);
+                else if (!xo && yo) FU_CALL(false, true, false);
+                else FU_CALL(true, true, false);
+            } else {
+                if (!xo && !yo) FU_CALL(false, false, true);
+                else if (xo && !yo) FU_CALL(true, false, true);
+                else if (!xo && yo) FU_CALL(false, true, true);
+                else FU_CALL(true, true, true);
+            }
+#undef FU_CALL
+        }
+        __syncthreads();                                       // the next tile's stage 1 overwrites the windows
+    }
+    if (alive) store_pixels<CN, 4>(acc, wacc, canvas, cstride, canvas_f32, cw, x0, y0, nx, ny);   // ragged cells without a visit: zeros
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2440,6 +2883,12 @@ struct sr_blend_plan {
     int n_edge_blocks = 0;
     int *d_cand_off = nullptr, *d_cand_idx = nullptr;   // per 256 x 8 block: candidate tiles (CSR, list order)
     bool weights_ready = false;                         // weight pyramids of the classes are in the arena
+    // fused final gather (k_final_fused): its own block tables -- regular blocks of FU_BW x FU_BH, edge blocks of
+    // 256 x 16 / 32 x 128 pixels holding every 4 x 4 cell that has a border visit
+    bool fused = false;
+    int *d_fcand_off = nullptr, *d_fcand_idx = nullptr, *d_fedge_cand = nullptr;
+    int4 *d_fedge_blocks = nullptr;
+    int n_fedge_blocks = 0;
     std::vector<char> sh_srcs, sh_fdesc;                // host shadows of d_srcs / d_fdesc (upload_if_changed)
     CachedTable subset_tabs[4];                         // compacted {TileDev, TileSrc} tables of recent tile subsets
     int subset_next = 0;
@@ -2815,6 +3264,10 @@ int sr_blend_plan_destroy(sr_blend_plan *plan)
         if (plan->d_edge_blocks) (void)hipFree(plan->d_edge_blocks);
         if (plan->d_edge_cand) (void)hipFree(plan->d_edge_cand);
         if (plan->d_cand_off) (void)hipFree(plan->d_cand_off);
+        if (plan->d_fcand_off) (void)hipFree(plan->d_fcand_off);
+        if (plan->d_fcand_idx) (void)hipFree(plan->d_fcand_idx);
+        if (plan->d_fedge_blocks) (void)hipFree(plan->d_fedge_blocks);
+        if (plan->d_fedge_cand) (void)hipFree(plan->d_fedge_cand);
         for (auto &t : plan->subset_tabs)
             if (t.d) (void)hipFree(t.d);
         if (plan->d_cand_idx) (void)hipFree(plan->d_cand_idx);
@@ -2982,6 +3435,13 @@ int sr_blend_plan_create(sr_ctx *ctx, const sr_tile_rect *h_tiles, int n, int cn
         D.fw = T.fw; D.lut_off = T.lut_off; D.nl = T.nl;
         D.H1 = T.nl > 1 ? T.H[1] : 1; D.W1 = T.nl > 1 ? T.W[1] : 1; D.P1 = T.nl > 1 ? T.P[1] : 16;
         D.g1 = T.nl > 1 ? T.g_off[1] : 0; D.r1 = T.nl > 1 ? T.r_off[1] : 0;
+        D.H2 = T.nl > 2 ? T.H[2] : 1; D.W2 = T.nl > 2 ? T.W[2] : 1; D.P2 = T.nl > 2 ? T.P[2] : 16;
+        D.g2 = T.nl > 2 ? T.g_off[2] : 0; D.r2 = T.nl > 2 ? T.r_off[2] : 0;
+        D.w1 = T.nl > 1 ? T.w_off[1] : 0;
+    }
+    {
+        const char *env = std::getenv("SR_FUSED_FINAL");
+        P->fused = (cn == 3 || cn == 1) && (env && env[0] == '1');      // opt-in while it is being tuned
     }
     if ((e = hipMalloc((void **)&P->d_luts, sizeof(float) * P->luts.size())) != hipSuccess) return fail(e, "luts");
     {
@@ -3072,6 +3532,107 @@ int sr_blend_plan_create(sr_ctx *ctx, const sr_tile_rect *h_tiles, int n, int cn
         if ((e = hipMalloc((void **)&P->d_cand_idx, sizeof(int) * cidx.size())) != hipSuccess) return fail(e, "candidate table");
         if ((e = hipMemcpy(P->d_cand_off, coff.data(), sizeof(int) * coff.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload");
         if ((e = hipMemcpy(P->d_cand_idx, cidx.data(), sizeof(int) * cidx.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload");
+    }
+    if (P->fused) {
+        // ---- tables of the fused gather ---------------------------------------------------------------------------------
+        const int rows = row_end - row_begin;
+        // host mirror of cell_is_interior (device): a 4 x 4 cell at tile-local (lx0, ly0), nx x ny of it on the strip
+        auto cell_interior = [](const TileDev &T, long long lx0, long long ly0, int nx, int ny) {
+            if (nx != 4 || ny != 4 || lx0 < 0 || ly0 < 0 || lx0 + 3 >= T.w || ly0 + 3 >= T.h) return false;
+            if (T.nl > 1) {
+                const long long r0 = (ly0 - 1) >> 1, c0 = (lx0 - 1) >> 1;
+                return c0 >= 0 && c0 + 3 <= T.W[1] - 1 && r0 >= 0 && r0 + 3 <= T.H[1] - 1;
+            }
+            return true;
+        };
+        const int enbx = (canvas_w + 255) / 256, enby = (rows + 15) / 16;        // shape 0: 256 x 16
+        const int enbx2 = (canvas_w + 31) / 32, enby2 = (rows + 127) / 128;      // shape 1: 32 x 128
+        std::vector<unsigned char> m0((size_t)std::max(enbx, 1) * std::max(enby, 1), 0), m1((size_t)std::max(enbx2, 1) * std::max(enby2, 1), 0);
+        // Every cell with a border visit lies within a few pixels of the edge line of the tile it visits (or on the
+        // ragged right / bottom end of the strip): walk the cells of a 24-pixel frame around each tile's outline, test
+        // them exactly, mark the block that holds them -- blocks along horizontal lines in shape 0, along vertical
+        // lines in shape 1 (a corner cell may be marked in both: computed twice, identical bytes).
+        auto scan = [&](const TileDev &T, long long xa, long long ya, long long xb, long long yb, int shape) {   // canvas px, half-open
+            xa = std::max<long long>(xa, 0); xb = std::min<long long>(xb, canvas_w);
+            ya = std::max<long long>(ya, row_begin); yb = std::min<long long>(yb, row_end);
+            if (xa >= xb || ya >= yb) return;
+            for (long long cy = (ya - row_begin) / 4; cy <= (yb - 1 - row_begin) / 4; ++cy)
+                for (long long cx = xa / 4; cx <= (xb - 1) / 4; ++cx) {
+                    const long long x0 = cx * 4, y0 = row_begin + cy * 4;
+                    const int nx = (int)std::min<long long>(4, canvas_w - x0), ny = (int)std::min<long long>(4, row_end - y0);
+                    const long long lx0 = x0 - T.x, ly0 = y0 - T.y;
+                    if (lx0 + nx <= 0 || ly0 + ny <= 0 || lx0 >= T.w || ly0 >= T.h) continue;
+                    if (cell_interior(T, lx0, ly0, nx, ny)) continue;
+                    if (shape == 0) m0[(size_t)((y0 - row_begin) / 16) * enbx + x0 / 256] = 1;
+                    else m1[(size_t)((y0 - row_begin) / 128) * enbx2 + x0 / 32] = 1;
+                }
+        };
+        const long long F = 24;
+        for (int t = 0; t < n && rows > 0; ++t) {
+            const TileDev &T = P->tiles[t];
+            const long long xa = T.x, xb = (long long)T.x + T.w, ya = T.y, yb = (long long)T.y + T.h;
+            scan(T, xa - F, ya - F, xb + F, ya + F, 0);
+            scan(T, xa - F, yb - F, xb + F, yb + F, 0);
+            scan(T, xa - F, ya - F, xa + F, yb + F, 1);
+            scan(T, xb - F, ya - F, xb + F, yb + F, 1);
+            // the ragged ends of the strip (cells narrower / shorter than 4): border visits of every tile they touch
+            if (canvas_w % 4) scan(T, canvas_w - (canvas_w % 4), row_begin, canvas_w, row_end, 1);
+            if (rows % 4) scan(T, 0, row_end - (rows % 4), canvas_w, row_end, 0);
+        }
+        std::vector<int4> eb;
+        for (int by = 0; by < enby; ++by)
+            for (int bx = 0; bx < enbx; ++bx)
+                if (m0[(size_t)by * enbx + bx]) eb.push_back(make_int4(bx * 256, row_begin + by * 16, 0, 0));
+        for (int by = 0; by < enby2; ++by)
+            for (int bx = 0; bx < enbx2; ++bx)
+                if (m1[(size_t)by * enbx2 + bx]) eb.push_back(make_int4(bx * 32, row_begin + by * 128, 1, 0));
+        std::vector<int> ecand;
+        for (auto &e4 : eb) {
+            const long long bx0 = e4.x, by0 = e4.y;
+            const long long bx1 = std::min<long long>(bx0 + (e4.z ? 32 : 256), canvas_w);
+            const long long by1 = std::min<long long>(by0 + (e4.z ? 128 : 16), row_end);
+            e4.w = (int)ecand.size();
+            for (int t = 0; t < n; ++t) {
+                const TileDev &T = P->tiles[t];
+                if (T.x < bx1 && (long long)T.x + T.w > bx0 && T.y < by1 && (long long)T.y + T.h > by0) ecand.push_back(t);
+            }
+        }
+        eb.push_back(make_int4(0, 0, 0, (int)ecand.size()));
+        P->n_fedge_blocks = (int)eb.size() - 1;
+        if ((e = hipMalloc((void **)&P->d_fedge_blocks, sizeof(int4) * eb.size())) != hipSuccess) return fail(e, "fused edge blocks");
+        if ((e = hipMemcpy(P->d_fedge_blocks, eb.data(), sizeof(int4) * eb.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload");
+        if ((e = hipMalloc((void **)&P->d_fedge_cand, sizeof(int) * std::max<size_t>(ecand.size(), 1))) != hipSuccess) return fail(e, "fused edge candidates");
+        if (!ecand.empty() && (e = hipMemcpy(P->d_fedge_cand, ecand.data(), sizeof(int) * ecand.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload");
+        // candidate tiles per regular block (FU_BW x FU_BH), CSR, list order
+        const int nbx_r = std::max((canvas_w + FU_BW - 1) / FU_BW, 1), nby_r = std::max((rows + FU_BH - 1) / FU_BH, 1);
+        const size_t nblk = (size_t)nbx_r * nby_r;
+        std::vector<int> coff(nblk + 1, 0);
+        auto block_span = [&](const TileDev &T, int &bx_a, int &bx_b, int &by_a, int &by_b) {
+            const long long x0 = std::max<long long>(T.x, 0), x1 = std::min<long long>((long long)T.x + T.w, canvas_w);
+            const long long y0 = std::max<long long>(T.y, row_begin), y1 = std::min<long long>((long long)T.y + T.h, row_end);
+            if (x0 >= x1 || y0 >= y1) return false;
+            bx_a = (int)(x0 / FU_BW); bx_b = (int)((x1 - 1) / FU_BW);
+            by_a = (int)((y0 - row_begin) / FU_BH); by_b = (int)((y1 - 1 - row_begin) / FU_BH);
+            return true;
+        };
+        for (int t = 0; t < n && rows > 0; ++t) {
+            int bxa, bxb, bya, byb;
+            if (!block_span(P->tiles[t], bxa, bxb, bya, byb)) continue;
+            for (int by = bya; by <= byb; ++by)
+                for (int bx = bxa; bx <= bxb; ++bx) ++coff[(size_t)by * nbx_r + bx + 1];
+        }
+        for (size_t i = 0; i < nblk; ++i) coff[i + 1] += coff[i];
+        std::vector<int> cidx((size_t)std::max(coff[nblk], 1), 0), fill(coff.begin(), coff.end() - 1);
+        for (int t = 0; t < n && rows > 0; ++t) {
+            int bxa, bxb, bya, byb;
+            if (!block_span(P->tiles[t], bxa, bxb, bya, byb)) continue;
+            for (int by = bya; by <= byb; ++by)
+                for (int bx = bxa; bx <= bxb; ++bx) cidx[(size_t)fill[(size_t)by * nbx_r + bx]++] = t;
+        }
+        if ((e = hipMalloc((void **)&P->d_fcand_off, sizeof(int) * coff.size())) != hipSuccess) return fail(e, "fused candidate table");
+        if ((e = hipMalloc((void **)&P->d_fcand_idx, sizeof(int) * cidx.size())) != hipSuccess) return fail(e, "fused candidate table");
+        if ((e = hipMemcpy(P->d_fcand_off, coff.data(), sizeof(int) * coff.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload");
+        if ((e = hipMemcpy(P->d_fcand_idx, cidx.data(), sizeof(int) * cidx.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload");
     }
     if ((e = hipMemcpyAsync(P->d_tiles, P->tiles.data(), sizeof(TileDev) * n, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e, "upload");
     if ((e = hipMemcpyAsync(P->d_classes, P->classes.data(), sizeof(TileDev) * P->classes.size(), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e, "upload");
@@ -3224,8 +3785,8 @@ static int blend_pyramids(sr_blend_plan *P, int dtype, void *const *h_d_tiles, c
     }
     int rc = check_launch("down chain");
     if (rc) return rc;
-    // collapse chain: levels max_nl-1 .. 1
-    for (int i = max_nl - 1; i >= 1; --i) {
+    // collapse chain: levels max_nl-1 .. 1 (.. 2 when the gather is fused: it builds R_1 itself, in LDS)
+    for (int i = max_nl - 1; i >= (P->fused ? 2 : 1); --i) {
         if (max_r[i] <= 0) continue;
         ProfScope ps(ctx, "up_level");
         if (P->cn == 3 || P->cn == 1) {
@@ -3261,7 +3822,17 @@ static int blend_gather(sr_blend_plan *P, bool lap, int dtype, void *const *h_d_
     dim3 block(64, 4);
     {
         ProfScope ps(ctx, lap ? "final_gather" : "weighted_gather");
-        if (P->cn == 3 || P->cn == 1) {
+        if (lap && P->fused) {
+            const int nbx_r = std::max((P->canvas_w + FU_BW - 1) / FU_BW, 1), nby_r = std::max((rows + FU_BH - 1) / FU_BH, 1);
+            dim3 grid((unsigned)(P->n_fedge_blocks + (long long)nbx_r * nby_r)), blk1(256);
+#define LAUNCH_FUSED(DT, CNV)                                                                                          \
+    hipLaunchKernelGGL((k_final_fused<DT, CNV>), grid, blk1, 0, ctx->stream, P->d_fdesc, P->d_fcand_off, P->d_fcand_idx,  \
+                       P->d_fedge_blocks, P->d_fedge_cand, P->n_fedge_blocks, nbx_r, P->d_arena, P->d_luts, d_canvas,   \
+                       (long long)canvas_stride, d_canvas_f32, P->canvas_w, P->row_begin, P->row_end)
+            if (P->cn == 3) { if (dtype == SR_U8) LAUNCH_FUSED(SRC_U8, 3); else LAUNCH_FUSED(SRC_F32, 3); }
+            else            { if (dtype == SR_U8) LAUNCH_FUSED(SRC_U8, 1); else LAUNCH_FUSED(SRC_F32, 1); }
+#undef LAUNCH_FUSED
+        } else if (P->cn == 3 || P->cn == 1) {
             const int nbx_r = std::max((P->canvas_w + FIN_BW - 1) / FIN_BW, 1), nby_r = std::max((rows + FIN_BH - 1) / FIN_BH, 1);
             dim3 grid((unsigned)(P->n_edge_blocks + (long long)nbx_r * nby_r));     // edge blocks first, then the regular ones
 #define LAUNCH_BLK(DT, LAPV, CNV)                                                                               \

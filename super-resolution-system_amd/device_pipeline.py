@@ -316,6 +316,8 @@ class DevicePipeline:
         self._deferred = None         # slot whose metric all-reduce is still to be posted
         self._done = 0                # canvas / result slot of the last finished image
         self._first = True
+        self.exchange_wait_s = 0.0    # host time spent in wait() of the exchange work handles (N > 1 diagnostics)
+        self.exchange_waits = 0
 
     # set 0 under the names the single-step path and the tests use
     @property
@@ -438,8 +440,13 @@ class DevicePipeline:
         staged = bool(pending) and self._first
         if staged:
             self.plan.pyramids(ptrs, self._strides, self._local_needed, first=True)
-        for w in pending or ():
-            w.wait()
+        if pending:
+            import time as _time
+            t_w = _time.perf_counter()
+            for w in pending:
+                w.wait()
+            self.exchange_wait_s += _time.perf_counter() - t_w
+            self.exchange_waits += 1
         self._first = False
         nk = (k + 1) % len(self.sets)
         overlap = next_image is not None and nk != k

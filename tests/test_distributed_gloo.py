@@ -176,3 +176,30 @@ def test_bench_self_launch_reaches_the_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=env, capture_output=True,
                        text=True, timeout=120)
     assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_bench_launcher_deadline_names_the_stuck_rank():
+    """Ranks that never come back (here: they sleep right after start-up, as ranks stuck in an RCCL call would) must not
+    leave the launcher waiting for the driver's kill: after --deadline-s it terminates them, prints every rank's last
+    completed stage and returns 124.  A rank that FAILS stops the others at once with its status."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update({"SR_DIST_BACKEND": "gloo", "SR_BENCH_TEST_HANG_RANKS": "0,1"})
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--deadline-s", "4"]
+    t0 = time.monotonic()
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 124 and time.monotonic() - t0 < 120, (r.returncode, r.stderr[-800:])
+    assert "deadline of 4 s passed with 2 of 2 ranks still running" in r.stderr
+    for rank in (0, 1):
+        assert f"rank {rank} [running] last completed stage: process started" in r.stderr
+    assert r.stdout.strip() == ""
+    import _native
+    if _native.device_count() == 0:
+        env["SR_BENCH_TEST_HANG_RANKS"] = "1"           # rank 0 fails its device check (rc 2) while rank 1 sleeps
+        t0 = time.monotonic()
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 2 and time.monotonic() - t0 < 120, (r.returncode, r.stderr[-800:])
+        assert "rank 0 exited with status 2; stopping the others" in r.stderr

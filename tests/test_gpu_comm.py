@@ -193,3 +193,38 @@ def test_one_rccl_and_one_rocm_smi_mapped(ctx):
         if created:
             dist.destroy_process_group()
         comm.close()
+
+
+def test_bench_two_rank_rehearsal_matches_one_rank():
+    """The driver's scale command has a tested twin: `SR_DIST_BACKEND=gloo python bench.py --gpus 2 --workload 4MP` -- the
+    self-launcher plus two ranks sharing this GPU (3 processes; rows staged through the host, flagged as a rehearsal) --
+    prints ONE JSON line with n_gpus 2 / strips2, per-rank exchange records, and exactly the scores of the 1-rank run."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    common = ["--workload", "4MP", "--steps", "2", "--warmup", "1", "--sweep", "none", "--no-pcie", "--no-cpu-baseline"]
+
+    def run(extra_env, args):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args + common, env={**env, **extra_env},
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        return json.loads(lines[0])
+
+    two = run({"SR_DIST_BACKEND": "gloo"}, ["--gpus", "2", "--deadline-s", "500"])
+    one = run({}, ["--gpus", "1"])
+    assert two["n_gpus"] == 2 and two["config"]["parallelism"] == "strips2" and two["scaling"] == "strong"
+    assert "REHEARSAL" in two["data"] and one["data"] == "synthetic"
+    assert two["quality"]["psnr"] == one["quality"]["psnr"]
+    for k in ("ssim_uniform", "ssim_gauss", "ssim_simple"):
+        assert two["quality"][k] == pytest.approx(one["quality"][k], rel=1e-12)
+    b = two["config"]["strip_bounds"]
+    assert b[0] == 0 and b[-1] == 1640 and len(b) == 3
+    assert [r["rank"] for r in two["ranks"]] == [0, 1]
+    assert sum(r["exchange_bytes_in"] for r in two["ranks"]) == sum(r["exchange_bytes_out"] for r in two["ranks"]) > 0
+    assert all(r["strip_rows"] == [b[i], b[i + 1]] for i, r in enumerate(two["ranks"]))
