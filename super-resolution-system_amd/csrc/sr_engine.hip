@@ -1237,32 +1237,37 @@ __global__ __launch_bounds__(256, SR_FINAL_WAVES) void k_final_fast(const FinalD
 // (12 B written + 12-18 B re-read per level-1 pixel), one launch, and the 3 x re-read of level-1 rows (a thread's 4 x 4
 // pixels share 4 level-1 rows; a block's window is fetched once, coalesced).  Same fp32 expression order everywhere:
 // bit-identical to the unfused path.
-//   regular block: 128 x 32 canvas pixels, 256 threads of 4 x 4 pixels; level-1 window <= 20 rows x 72 columns per plane
+//   regular block: 128 x 32 canvas pixels, 512 threads of 4 x 2 pixels; level-1 window <= 20 rows x 72 columns per plane
 //   edge blocks (cells with a border visit): 256 x 16 or 32 x 128 pixels, generic per-pixel border rules, same windows
+// The kernels of this path issue at one VALU instruction per 4 cycles and wave whatever the type, so the lever is the
+// instruction count: the two LDS windows are interleaved per pixel and every pyrUp step runs on (g, r) pairs in v_pk_*.
 // ---------------------------------------------------------------------------------------------
+#ifndef FU_THREADS
+#define FU_THREADS 256        /* threads (= 4 x 2 cells) per block */
+#endif
+#ifndef FU_WAVES
+#define FU_WAVES 4           /* waves per SIMD the register allocation is held to */
+#endif
 #define FU_BW 128
-#define FU_BH 32
+#define FU_BH (FU_THREADS / 16)             /* 32 cells across, FU_THREADS / 32 cell rows of 2 pixels */
+#define FU_E0H (FU_THREADS / 32)            /* edge shape 0: 256 x FU_E0H pixels (64 cells across) */
+#define FU_E1W 16                           /* edge shape 1: FU_E1W x FU_E1H pixels (4 cells across: a vertical tile edge
+                                               makes 1 - 3 of them border cells) */
+#define FU_E1H (FU_THREADS / 2)
 #define FU_LP 72              /* LDS pitch (floats) of a regular block's window: 18 patches of 4 columns */
-#define FU_PLANE 1632         /* floats per (array, plane) window: 20 x 72 regular, 12 x 136 / 68 x 24 edge shapes */
-
-// Is the thread's 4 x 4 rectangle an interior visit of tile D (all sixteen pixels inside, every level-1 tap of the fast
-// path inside the level and away from its borders)?  Regular and edge blocks evaluate this same test.
-__device__ __forceinline__ bool cell_is_interior(const FinalDesc &D, int lx0, int ly0, int nx, int ny)
-{
-    if (nx != 4 || ny != 4 || lx0 < 0 || ly0 < 0 || lx0 + 3 >= D.w || ly0 + 3 >= D.h) return false;
-    if (D.nl > 1) {
-        const int r0 = (ly0 - 1) >> 1, c0 = (lx0 - 1) >> 1;
-        return c0 >= 0 && c0 + 3 <= D.W1 - 1 && r0 >= 0 && r0 + 3 <= D.H1 - 1;
-    }
-    return true;
-}
+/* pixels per plane window (two floats each): rows = block rows / 2 + 3, rounded up to even; 72 (regular), 136 (shape 0) or
+   24 (shape 1) columns */
+#define FU_ROWS_EVEN(bh) ((((bh) / 2 + 3) + 1) / 2 * 2)
+#define FU_MAX3(a, b, c) ((a) > (b) ? ((a) > (c) ? (a) : (c)) : ((b) > (c) ? (b) : (c)))
+#define FU_E1LP (((FU_E1W / 2 + 2 + 3) + 3) / 4 * 4)      /* window columns of shape 1, whole patches */
+#define FU_PLANE FU_MAX3(FU_ROWS_EVEN(FU_BH) * 72, FU_ROWS_EVEN(FU_E0H) * 136, FU_ROWS_EVEN(FU_E1H) * FU_E1LP)
 
 // The level-1 window (tile coordinates) a block of bw x bh canvas pixels at tile-local (lxa, lya) samples: rows R0 ..,
 // columns C0 .. in patches of 2 rows x 4 columns (R0 even, C0 a multiple of 4: the alignment k_up_level_blk's threads have).
 __device__ __forceinline__ bool fused_window(const FinalDesc &D, int lxa, int lya, int bw, int bh, int &R0, int &C0, int &npr, int &npc)
 {
     const int c_lo = max((lxa - 1) >> 1, 0), r_lo = max((lya - 1) >> 1, 0);
-    const int c_hi = min(((lxa + bw - 5) >> 1) + 3, D.W1 - 1), r_hi = min(((lya + bh - 5) >> 1) + 3, D.H1 - 1);
+    const int c_hi = min(((lxa + bw - 5) >> 1) + 3, D.W1 - 1), r_hi = min(((lya + bh - 3) >> 1) + 2, D.H1 - 1);
     C0 = c_lo & ~3;
     R0 = r_lo & ~1;
     if (c_hi < C0 || r_hi < R0) return false;
@@ -1271,23 +1276,30 @@ __device__ __forceinline__ bool fused_window(const FinalDesc &D, int lxa, int ly
     return true;
 }
 
-// Stage 1: R_1 and G_1 of the window into LDS.  One item = one 4 x 2 patch of one plane = up_level_thread's work.
+// Stage 1: R_1 and G_1 of the window into LDS, interleaved per pixel as (g, r) pairs: lds[plane][row][col][2] -- stage 2
+// then reads a pixel's two values as one aligned 8-byte pair and runs the pyrUp of both arrays in packed fp32 (v_pk_*,
+// IEEE per element: same roundings as the scalar form).  One item = one 4 x 2 patch of one plane = up_level_thread's work.
 template <int CN>
 __device__ __forceinline__ void fused_stage1(const FinalDesc &D, const float *__restrict__ arena, float *lds, int R0, int C0,
                                              int npr, int npc, int LP, int tid)
 {
     const int per_plane = npr * npc, n_items = per_plane * CN;
     const size_t plane1 = (size_t)D.H1 * D.P1, plane2 = (size_t)D.H2 * D.P2;
-    for (int item = tid; item < n_items; item += 256) {
-        const int c = item / per_plane, rem = item - c * per_plane;
-        const int pr = rem / npc, pc = rem - pr * npc;
+    // item -> (plane, patch row, patch column) with multiply-shift divisions (x < 1024, divisor d <= 256, m = ceil(2^20 / d):
+    // exact because x * (m * d - 2^20) < 1024 * 256 < 2^20)
+    const unsigned m_pp = ((1u << 20) + per_plane - 1) / per_plane, m_pc = ((1u << 20) + npc - 1) / npc;
+    for (int item = tid; item < n_items; item += FU_THREADS) {
+        const int c = (int)(((unsigned)item * m_pp) >> 20), rem = item - c * per_plane;
+        const int pr = (int)(((unsigned)rem * m_pc) >> 20), pc = rem - pr * npc;
         const int px = C0 + 4 * pc, py = R0 + 2 * pr;
         if (px >= D.W1 || py >= D.H1) continue;
-        const bool two = py + 1 < D.H1;
+        // every load of the item is issued before the first use (no branch between them: a conditional second row would
+        // put a full memory round trip between the two halves); a patch on the last odd row re-reads its own row
+        const int row1 = (py + 1 < D.H1) ? D.P1 : 0;
         const float *g = arena + D.g1 + c * plane1 + (size_t)py * D.P1 + px;
         const float *wr = arena + D.w1 + (size_t)py * D.P1 + px;
-        const f4_t g0v = ld_f4(g), g1v = two ? ld_f4(g + D.P1) : g0v;
-        const f4_t w0v = ld_f4(wr), w1v = two ? ld_f4(wr + D.P1) : w0v;
+        const f4_t g0v = ld_f4(g), g1v = ld_f4(g + row1);
+        const f4_t w0v = ld_f4(wr), w1v = ld_f4(wr + row1);
         f4_t o0, o1;
         if (D.nl == 2) {                         // level 1 is the top of this tile's pyramid: R = G * W
             o0 = g0v * w0v;
@@ -1313,33 +1325,38 @@ __device__ __forceinline__ void fused_stage1(const FinalDesc &D, const float *__
             o1.z = ur[1][2] + (g1v.z - ug[1][2]) * w1v.z;
             o1.w = ur[1][3] + (g1v.w - ug[1][3]) * w1v.w;
         }
-        float *dg = lds + c * FU_PLANE + (pr * 2) * LP + pc * 4;
-        float *dr = dg + CN * FU_PLANE;
-        st_f4(dg, g0v);
-        st_f4(dg + LP, g1v);
-        st_f4(dr, o0);
-        st_f4(dr + LP, o1);
+        // (g, r) pairs, 32 contiguous bytes per patch row: 16-byte stores (dword stores at a 32-byte lane stride would hit
+        // every LDS bank eight times)
+        float *d0 = lds + c * (2 * FU_PLANE) + ((pr * 2) * LP + pc * 4) * 2;
+        float *d1 = d0 + 2 * LP;
+        f4_t s0, s1, s2, s3;
+        s0.x = g0v.x; s0.y = o0.x; s0.z = g0v.y; s0.w = o0.y; s1.x = g0v.z; s1.y = o0.z; s1.z = g0v.w; s1.w = o0.w;
+        s2.x = g1v.x; s2.y = o1.x; s2.z = g1v.y; s2.w = o1.y; s3.x = g1v.z; s3.y = o1.z; s3.z = g1v.w; s3.w = o1.w;
+        st_f4(d0, s0);
+        st_f4(d0 + 4, s1);
+        st_f4(d1, s2);
+        st_f4(d1 + 4, s3);
     }
 }
 
-// pyrUp of a 4-row x 4-column register neighbourhood -> the thread's 4 x 4 pixels (interior form; see up_regs for the
-// folded power-of-two factors).  Canvas rows j = 0..3 sample level-1 rows r0 .. r0 + 3.
+// pyrUp of a 3-row x 4-column neighbourhood of (g, r) PAIRS -> the thread's 4 x 2 pixels, both arrays at once in packed
+// fp32 (interior form; up_regs with pairs).  q[r][i] is the pair at row r0 + r, column c0 + i.
 template <bool XO, bool YO>
-__device__ __forceinline__ void up_regs4(const f4_t (&q)[4], float (&u)[4][4])
+__device__ __forceinline__ void up_pairs(const f2_t (&q)[3][4], f2_t (&u)[2][4])
 {
-    float h[4][4];
+    f2_t h[3][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < 3; ++r) {
         if (!XO) {
-            h[r][0] = (q[r].x + q[r].y * 6.0f) + q[r].z;
-            h[r][1] = q[r].y + q[r].z;
-            h[r][2] = (q[r].y + q[r].z * 6.0f) + q[r].w;
-            h[r][3] = q[r].z + q[r].w;
+            h[r][0] = (q[r][0] + q[r][1] * 6.0f) + q[r][2];
+            h[r][1] = q[r][1] + q[r][2];
+            h[r][2] = (q[r][1] + q[r][2] * 6.0f) + q[r][3];
+            h[r][3] = q[r][2] + q[r][3];
         } else {
-            h[r][0] = q[r].x + q[r].y;
-            h[r][1] = (q[r].x + q[r].y * 6.0f) + q[r].z;
-            h[r][2] = q[r].y + q[r].z;
-            h[r][3] = (q[r].y + q[r].z * 6.0f) + q[r].w;
+            h[r][0] = q[r][0] + q[r][1];
+            h[r][1] = (q[r][0] + q[r][1] * 6.0f) + q[r][2];
+            h[r][2] = q[r][1] + q[r][2];
+            h[r][3] = (q[r][1] + q[r][2] * 6.0f) + q[r][3];
         }
     }
 #pragma unroll
@@ -1347,123 +1364,120 @@ __device__ __forceinline__ void up_regs4(const f4_t (&q)[4], float (&u)[4][4])
         const bool kodd = XO ? ((k & 1) == 0) : ((k & 1) == 1);
         const float ce = kodd ? (1.0f / 16.0f) : (1.0f / 64.0f);
         const float co = kodd ? (1.0f / 4.0f) : (1.0f / 16.0f);
+        const f2_t ev = ((h[0][k] + h[1][k] * 6.0f) + h[2][k]) * ce;
         if (!YO) {
-            u[0][k] = ((h[0][k] + h[1][k] * 6.0f) + h[2][k]) * ce;
+            u[0][k] = ev;
             u[1][k] = (h[1][k] + h[2][k]) * co;
-            u[2][k] = ((h[1][k] + h[2][k] * 6.0f) + h[3][k]) * ce;
-            u[3][k] = (h[2][k] + h[3][k]) * co;
         } else {
             u[0][k] = (h[0][k] + h[1][k]) * co;
-            u[1][k] = ((h[0][k] + h[1][k] * 6.0f) + h[2][k]) * ce;
-            u[2][k] = (h[1][k] + h[2][k]) * co;
-            u[3][k] = ((h[1][k] + h[2][k] * 6.0f) + h[3][k]) * ce;
+            u[1][k] = ev;
         }
     }
 }
 
-// weights of an interior 4 x 4 visit (tile_weights_interior for four rows)
-__device__ __forceinline__ void cell_weights_interior(const FinalDesc &D, const float *__restrict__ luts, int lx0, int ly0,
-                                                      float (&w0)[4][4])
-{
-    const int dmin = min(min(ly0, D.h - 4 - ly0), min(lx0, D.w - 4 - lx0));
-    const float *lut = luts + D.lut_off;
-    if (dmin >= D.fw) {
-        const float wf = lut[D.fw];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) w0[j][k] = wf;
-        return;
-    }
-    float fy[4], fx[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) fy[j] = lut[min(min(ly0 + j, D.h - 1 - ly0 - j), D.fw)];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) fx[k] = lut[min(min(lx0 + k, D.w - 1 - lx0 - k), D.fw)];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) w0[j][k] = __builtin_fminf(fy[j], fx[k]);
-}
+// Stage 2, interior visit of a regular block: the thread's 4 x 2 pixels from the LDS window (pitch FU_LP pairs).  CODD: the
+// first tap column is odd -- its 32 bytes per row are then 8-byte aligned only and read as 8 + 16 + 8.
+// the level-0 pixels of an interior 4 x 2 visit: requested BEFORE the block's stage 1 so they arrive under it
+template <int DT, int CN>
+struct CellPixels {
+    float g0[(DT == SRC_U8 && CN == 3) ? 1 : 2][(DT == SRC_U8 && CN == 3) ? 1 : 4][CN];
+    u3_t qs[2];
+};
 
-// Stage 2, interior visit of a regular block: the thread's 4 x 4 pixels from the LDS windows (pitch FU_LP).  CODD: the
-// first tap column sits at an odd LDS column -- the taps are then read as three aligned 8-byte pairs instead of two.
-template <int DT, int CN, bool XO, bool YO, bool CODD>
-__device__ __forceinline__ void fused_gather_fast(const FinalDesc &D, const float *__restrict__ luts, const float *lds, int R0, int C0,
-                                                  int lx0, int ly0, float (&acc)[4][4][CN], float (&wacc)[4][4])
+template <int DT, int CN>
+__device__ __forceinline__ void fused_load_pixels(const FinalDesc &D, int lx0, int ly0, CellPixels<DT, CN> &px)
 {
-    const bool pyr = D.nl > 1;
-    float g0[4][4][CN];
-    u3_t qs[4];
     constexpr bool LAZY = (DT == SRC_U8 && CN == 3);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 2; ++j) {
         const char *srow = (const char *)D.src + (size_t)(ly0 + j) * D.stride;
         if (LAZY) {
-            qs[j] = ld_u3_a1_g(srow + (size_t)lx0 * 3);
+            px.qs[j] = ld_u3_a1_g(srow + (size_t)lx0 * 3);
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
 #pragma unroll
                 for (int c = 0; c < CN; ++c) {
-                    if (DT == SRC_U8) g0[j][k][c] = (float)((const unsigned char *)srow)[(lx0 + k) * CN + c];
-                    else g0[j][k][c] = ((const float *)srow)[(lx0 + k) * CN + c];
+                    if (DT == SRC_U8) px.g0[j][k][c] = (float)((const unsigned char *)srow)[(lx0 + k) * CN + c];
+                    else px.g0[j][k][c] = ((const float *)srow)[(lx0 + k) * CN + c];
                 }
         }
     }
-    float w0[4][4];
-    cell_weights_interior(D, luts, lx0, ly0, w0);
+}
+
+template <int DT, int CN, bool XO, bool YO, bool CODD>
+__device__ __forceinline__ void fused_gather_fast(const FinalDesc &D, const float *__restrict__ luts, const float *lds, int R0, int C0,
+                                                  int lx0, int ly0, const CellPixels<DT, CN> &cp, float (&acc)[2][4][CN],
+                                                  float (&wacc)[2][4])
+{
+    const bool pyr = D.nl > 1;
+    constexpr bool LAZY = (DT == SRC_U8 && CN == 3);
+    float w0[2][4];
+    tile_weights_interior(D, luts, lx0, ly0, w0);
     auto px = [&](int j, int k, int c) -> float {
         if (LAZY) {
             const int b = 3 * k + c;
-            unsigned wd = (b >> 2) == 0 ? qs[j].x : ((b >> 2) == 1 ? qs[j].y : qs[j].z);
+            unsigned wd = (b >> 2) == 0 ? cp.qs[j].x : ((b >> 2) == 1 ? cp.qs[j].y : cp.qs[j].z);
             asm volatile("" : "+v"(wd));      // keeps the conversion at its use (see gather_tile_fast)
             return (float)((wd >> (8 * (b & 3))) & 0xFFu);
         }
-        return g0[j][k][c];
+        return cp.g0[LAZY ? 0 : j][LAZY ? 0 : k][c];
     };
+    // beyond the feather width every weight of the cell is lut[fw]; where that is exactly 1 (linear and cosine ramps)
+    // for the whole wave, lap * w == lap and the multiplies are skipped -- wave-uniform branch, bit-identical
+    const bool flat = min(min(ly0, D.h - 2 - ly0), min(lx0, D.w - 4 - lx0)) >= D.fw && luts[D.lut_off + D.fw] == 1.0f;
+    const bool unit_w = __all(flat) != 0;
     if (pyr) {
         const int r0 = (ly0 - 1) >> 1, c0 = (lx0 - 1) >> 1;
-        const float *base = lds + (r0 - R0) * FU_LP + ((c0 - C0) & ~1);
+        // (g, r) pairs of rows r0 .. r0 + 2, columns c0 .. c0 + 3: 32 contiguous bytes per row
+        const float *base = lds + ((r0 - R0) * FU_LP + (c0 - C0)) * 2;
 #pragma unroll
         for (int c = 0; c < CN; ++c) {
-            float ug[4][4], ur[4][4];
+            const float *p = base + c * (2 * FU_PLANE);
+            f2_t q[3][4], u[2][4];
 #pragma unroll
-            for (int arr = 0; arr < 2; ++arr) {
-                const float *p = base + (arr * CN + c) * FU_PLANE;
-                f4_t q[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const f2_t a = *(const f2_t *)(p + r * FU_LP), b = *(const f2_t *)(p + r * FU_LP + 2);
-                    if (!CODD) {
-                        q[r].x = a.x; q[r].y = a.y; q[r].z = b.x; q[r].w = b.y;
-                    } else {
-                        const f2_t d = *(const f2_t *)(p + r * FU_LP + 4);
-                        q[r].x = a.y; q[r].y = b.x; q[r].z = b.y; q[r].w = d.x;
-                    }
+            for (int r = 0; r < 3; ++r) {
+                const float *pr = p + r * (2 * FU_LP);
+                if (!CODD) {
+                    const f4_t a = *(const f4_t *)pr, b = *(const f4_t *)(pr + 4);
+                    q[r][0].x = a.x; q[r][0].y = a.y; q[r][1].x = a.z; q[r][1].y = a.w;
+                    q[r][2].x = b.x; q[r][2].y = b.y; q[r][3].x = b.z; q[r][3].y = b.w;
+                } else {
+                    const f2_t a = *(const f2_t *)pr, d = *(const f2_t *)(pr + 6);
+                    const f4_t b = *(const f4_t *)(pr + 2);
+                    q[r][0] = a; q[r][1].x = b.x; q[r][1].y = b.y; q[r][2].x = b.z; q[r][2].y = b.w; q[r][3] = d;
                 }
-                if (arr == 0) up_regs4<XO, YO>(q, ug);
-                else up_regs4<XO, YO>(q, ur);
             }
+            up_pairs<XO, YO>(q, u);
+            if (unit_w) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float lap = px(j, k, c) - ug[j][k];
-                    const float wl = lap * w0[j][k];
-                    acc[j][k][c] += ur[j][k] + wl;
-                }
+                    for (int k = 0; k < 4; ++k) {
+                        const float lap = px(j, k, c) - u[j][k].x;
+                        acc[j][k][c] += u[j][k].y + lap;
+                    }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float lap = px(j, k, c) - u[j][k].x;
+                        const float wl = lap * w0[j][k];
+                        acc[j][k][c] += u[j][k].y + wl;
+                    }
+            }
         }
     } else {
 #pragma unroll
         for (int c = 0; c < CN; ++c)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) acc[j][k][c] += px(j, k, c) * w0[j][k];
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int k = 0; k < 4; ++k) wacc[j][k] += w0[j][k];
 }
@@ -1477,7 +1491,7 @@ __device__ __forceinline__ void up_block_win(const float *win, int hs, int ws, i
     for (int r = 0; r < 3; ++r) {
         const int ro = (min(max(r0 + r, 0), hs - 1) - R0) * LP - C0;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[r][c] = win[ro + min(max(c0 + c, 0), ws - 1)];
+        for (int c = 0; c < 4; ++c) v[r][c] = win[(ro + min(max(c0 + c, 0), ws - 1)) * 2];      // (g, r) pairs: stride 2
     }
     up_rows4<XO>(v, ws, c0, h);
     up_cols2<YO>(h, r0, u);
@@ -1497,8 +1511,8 @@ __device__ __forceinline__ void fused_gather_generic(const FinalDesc &D, const f
     for (int c = 0; c < CN; ++c) {
         float ug[2][4], ur[2][4];
         if (pyr) {
-            up_block_win<XO, YO>(lds + c * FU_PLANE, D.H1, D.W1, LP, R0, C0, r0, c0, ug);
-            up_block_win<XO, YO>(lds + (CN + c) * FU_PLANE, D.H1, D.W1, LP, R0, C0, r0, c0, ur);
+            up_block_win<XO, YO>(lds + c * (2 * FU_PLANE), D.H1, D.W1, LP, R0, C0, r0, c0, ug);
+            up_block_win<XO, YO>(lds + c * (2 * FU_PLANE) + 1, D.H1, D.W1, LP, R0, C0, r0, c0, ur);
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -1527,7 +1541,7 @@ __device__ __forceinline__ void fused_gather_generic(const FinalDesc &D, const f
             if (valid & (1u << (j * 4 + k))) wacc[j][k] += w0[j][k];
 }
 
-// Edge blocks of the fused gather: the 4 x 4 cells with a border visit, as two 4 x 2 generic visits each.
+// Edge blocks of the fused gather: the 4 x 2 cells with a border visit, generic per-pixel rules from the LDS window.
 template <int DT, int CN>
 __device__ __forceinline__ void fused_edge_block(const FinalDesc *__restrict__ descs, const int4 *__restrict__ edge_blocks, int ebi,
                                                  const int *__restrict__ cand_idx, const float *__restrict__ arena,
@@ -1537,31 +1551,29 @@ __device__ __forceinline__ void fused_edge_block(const FinalDesc *__restrict__ d
     const int4 eb = edge_blocks[ebi];
     const int c_begin = eb.w, c_end = edge_blocks[ebi + 1].w;
     const int tid = threadIdx.x;
-    const int shape = eb.z;                                   // 0: 256 x 16 px (64 x 4 cells), 1: 32 x 128 px (8 x 32 cells)
-    const int bw = shape ? 32 : 256, bh = shape ? 128 : 16, LP = shape ? 24 : 136;
-    const int x0 = eb.x + (shape ? (tid & 7) : (tid & 63)) * 4;
-    const int y0 = eb.y + (shape ? (tid >> 3) : (tid >> 6)) * 4;
+    const int shape = eb.z;                                   // 0: 256 x FU_E0H px (64 cells across), 1: FU_E1W x FU_E1H px (4 across)
+    const int bw = shape ? FU_E1W : 256, bh = shape ? FU_E1H : FU_E0H, LP = shape ? FU_E1LP : 136;
+    const int x0 = eb.x + (shape ? (tid & 3) : (tid & 63)) * 4;
+    const int y0 = eb.y + (shape ? (tid >> 2) : (tid >> 6)) * 2;
     const bool inside = x0 < cw && y0 < row_end;
-    const int nx = min(4, cw - x0), ny = min(4, row_end - y0);
+    const int nx = min(4, cw - x0), ny = min(2, row_end - y0);
     bool edge = false;
     if (inside)
         for (int i = c_begin; i < c_end; ++i) {
             const FinalDesc &D = descs[cand_idx[i]];
             const int lx0 = x0 - D.x, ly0 = y0 - D.y;
             if (lx0 + nx <= 0 || ly0 + ny <= 0 || lx0 >= D.w || ly0 >= D.h) continue;
-            if (!cell_is_interior(D, lx0, ly0, nx, ny)) edge = true;
+            if (!visit_is_interior<true>(D, lx0, ly0, nx, ny)) edge = true;
         }
-    float acc[2][2][4][CN], wacc[2][2][4];
+    float acc[2][4][CN], wacc[2][4];
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int k = 0; k < 4; ++k) {
+            wacc[j][k] = 0.f;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                wacc[hf][j][k] = 0.f;
-#pragma unroll
-                for (int c = 0; c < CN; ++c) acc[hf][j][k][c] = 0.f;
-            }
+            for (int c = 0; c < CN; ++c) acc[j][k][c] = 0.f;
+        }
     for (int i = c_begin; i < c_end; ++i) {
         const FinalDesc &D = descs[cand_idx[i]];
         int R0 = 0, C0 = 0, npr = 0, npc = 0;
@@ -1570,35 +1582,27 @@ __device__ __forceinline__ void fused_edge_block(const FinalDesc *__restrict__ d
         __syncthreads();
         const int lx0 = x0 - D.x, ly0 = y0 - D.y;
         if (edge && !(lx0 + nx <= 0 || ly0 + ny <= 0 || lx0 >= D.w || ly0 >= D.h)) {
+            unsigned valid = 0;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (j < ny && k < nx && lx0 + k >= 0 && lx0 + k < D.w && ly0 + j >= 0 && ly0 + j < D.h)
+                        valid |= 1u << (j * 4 + k);
             const bool xo = (D.x & 1) != 0;
             const bool yo = ((row_begin - D.y) & 1) != 0;
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const int ly = ly0 + 2 * hf;
-                unsigned valid = 0;
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (2 * hf + j < ny && k < nx && lx0 + k >= 0 && lx0 + k < D.w && ly + j >= 0 && ly + j < D.h)
-                            valid |= 1u << (j * 4 + k);
-                if (!valid) continue;
-                if (!xo && !yo) fused_gather_generic<DT, CN, false, false>(D, luts, lds, LP, R0, C0, lx0, ly, valid, acc[hf], wacc[hf]);
-                else if (xo && !yo) fused_gather_generic<DT, CN, true, false>(D, luts, lds, LP, R0, C0, lx0, ly, valid, acc[hf], wacc[hf]);
-                else if (!xo && yo) fused_gather_generic<DT, CN, false, true>(D, luts, lds, LP, R0, C0, lx0, ly, valid, acc[hf], wacc[hf]);
-                else fused_gather_generic<DT, CN, true, true>(D, luts, lds, LP, R0, C0, lx0, ly, valid, acc[hf], wacc[hf]);
-            }
+            if (!xo && !yo) fused_gather_generic<DT, CN, false, false>(D, luts, lds, LP, R0, C0, lx0, ly0, valid, acc, wacc);
+            else if (xo && !yo) fused_gather_generic<DT, CN, true, false>(D, luts, lds, LP, R0, C0, lx0, ly0, valid, acc, wacc);
+            else if (!xo && yo) fused_gather_generic<DT, CN, false, true>(D, luts, lds, LP, R0, C0, lx0, ly0, valid, acc, wacc);
+            else fused_gather_generic<DT, CN, true, true>(D, luts, lds, LP, R0, C0, lx0, ly0, valid, acc, wacc);
         }
-        __syncthreads();                                   // the next tile's stage 1 overwrites the windows
+        __syncthreads();                                   // the next tile's stage 1 overwrites the window
     }
-    if (!edge) return;
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
-        if (2 * hf < ny) store_pixels<CN>(acc[hf], wacc[hf], canvas, cstride, canvas_f32, cw, x0, y0 + 2 * hf, nx, min(2, ny - 2 * hf));
+    if (edge) store_pixels<CN>(acc, wacc, canvas, cstride, canvas_f32, cw, x0, y0, nx, ny);
 }
 
 template <int DT, int CN>
-__global__ __launch_bounds__(256, 3) void k_final_fused(const FinalDesc *__restrict__ descs, const int *__restrict__ cand_off,
+__global__ __launch_bounds__(FU_THREADS, FU_WAVES) void k_final_fused(const FinalDesc *__restrict__ descs, const int *__restrict__ cand_off,
                                                         const int *__restrict__ cand_idx, const int4 *__restrict__ edge_blocks,
                                                         const int *__restrict__ edge_cand, int n_edge, int nbx_r,
                                                         const float *__restrict__ arena, const float *__restrict__ luts,
@@ -1611,24 +1615,22 @@ __global__ __launch_bounds__(256, 3) void k_final_fused(const FinalDesc *__restr
                                  row_begin, row_end);
         return;
     }
+    // (Measured and rejected: a workgroup marching down several blocks of a column -- one dispatch, halo rows still in
+    // the CU's caches -- is slower, 1.37 -> 1.52 ms at 16 blocks: the blocks of a march run strictly one after the other
+    // and each is a chain of dependent memory round trips; independent blocks overlap them.)
     const int blk = (int)blockIdx.x - n_edge;
     const int by = blk / nbx_r, bx = blk - by * nbx_r;
     const int c_begin = cand_off[blk], c_end = cand_off[blk + 1];
     const int tid = threadIdx.x;
     const int bx0 = bx * FU_BW, by0 = row_begin + by * FU_BH;
-    const int x0 = bx0 + (tid & 31) * 4, y0 = by0 + (tid >> 5) * 4;
-    const int nx = min(4, cw - x0), ny = min(4, row_end - y0);
-    // a cell with any border visit belongs to the edge blocks (which recompute every visit of it)
+    const int x0 = bx0 + (tid & 31) * 4, y0 = by0 + (tid >> 5) * 2;
+    const int nx = min(4, cw - x0), ny = min(2, row_end - y0);
+    // a cell with any border visit belongs to the edge blocks (which recompute every visit of it): it stops
+    // accumulating at its first border visit and stores nothing
     bool alive = x0 < cw && y0 < row_end;
-    for (int i = c_begin; i < c_end && alive; ++i) {
-        const FinalDesc &D = descs[cand_idx[i]];
-        const int lx0 = x0 - D.x, ly0 = y0 - D.y;
-        if (lx0 + nx <= 0 || ly0 + ny <= 0 || lx0 >= D.w || ly0 >= D.h) continue;
-        if (!cell_is_interior(D, lx0, ly0, nx, ny)) alive = false;
-    }
-    float acc[4][4][CN], wacc[4][4];
+    float acc[2][4][CN], wacc[2][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             wacc[j][k] = 0.f;
@@ -1640,14 +1642,18 @@ __global__ __launch_bounds__(256, 3) void k_final_fused(const FinalDesc *__restr
         const int lxa = bx0 - D.x, lya = by0 - D.y;
         int R0 = 0, C0 = 0, npr = 0, npc = 0;
         const bool win = D.nl > 1 && fused_window(D, lxa, lya, FU_BW, FU_BH, R0, C0, npr, npc);    // block-uniform
+        const int lx0 = x0 - D.x, ly0 = y0 - D.y;
+        bool visit = alive && !(lx0 + nx <= 0 || ly0 + ny <= 0 || lx0 >= D.w || ly0 >= D.h);
+        if (visit && !visit_is_interior<true>(D, lx0, ly0, nx, ny)) visit = alive = false;
+        CellPixels<DT, CN> cp;
+        if (visit) fused_load_pixels<DT, CN>(D, lx0, ly0, cp);                                     // in flight during stage 1
         if (win) fused_stage1<CN>(D, arena, lds, R0, C0, npr, npc, FU_LP, tid);
         __syncthreads();
-        const int lx0 = x0 - D.x, ly0 = y0 - D.y;
-        if (alive && !(lx0 + 4 <= 0 || ly0 + 4 <= 0 || lx0 >= D.w || ly0 >= D.h)) {
+        if (visit) {
             const bool xo = (D.x & 1) != 0;                      // x0 is a multiple of 4
-            const bool yo = ((row_begin - D.y) & 1) != 0;        // y0 - row_begin is a multiple of 4
+            const bool yo = ((row_begin - D.y) & 1) != 0;        // y0 - row_begin is a multiple of 2
             const bool codd = D.nl > 1 && ((((lxa - 1) >> 1) - C0) & 1) != 0;   // parity of every cell's first tap column (block-uniform)
-#define FU_CALL(XOV, YOV, CV) fused_gather_fast<DT, CN, XOV, YOV, CV>(D, luts, lds, R0, C0, lx0, ly0, acc, wacc)
+#define FU_CALL(XOV, YOV, CV) fused_gather_fast<DT, CN, XOV, YOV, CV>(D, luts, lds, R0, C0, lx0, ly0, cp, acc, wacc)
             if (!codd) {
                 if (!xo && !yo) FU_CALL(false, false, false);
                 else if (xo && !yo) FU_CALL(true, false, false);
@@ -1661,9 +1667,9 @@ __global__ __launch_bounds__(256, 3) void k_final_fused(const FinalDesc *__restr
             }
 #undef FU_CALL
         }
-        __syncthreads();                                       // the next tile's stage 1 overwrites the windows
+        __syncthreads();                                       // the next tile's stage 1 overwrites the window
     }
-    if (alive) store_pixels<CN, 4>(acc, wacc, canvas, cstride, canvas_f32, cw, x0, y0, nx, ny);   // ragged cells without a visit: zeros
+    if (alive) store_pixels<CN>(acc, wacc, canvas, cstride, canvas_f32, cw, x0, y0, nx, ny);   // ragged cells without a visit: zeros
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3304,6 +3310,10 @@ int sr_blend_plan_create(sr_ctx *ctx, const sr_tile_rect *h_tiles, int n, int cn
     P->row_end = row_end;
     P->tiles.resize(n);
     P->tile_rows.resize(n);
+    {
+        const char *env = std::getenv("SR_FUSED_FINAL");
+        P->fused = (cn == 3 || cn == 1) && !(env && env[0] == '0');     // SR_FUSED_FINAL=0: the unfused pair (A/B runs)
+    }
 
     std::map<std::pair<int, int>, int> cls_of;
     std::vector<SrTileLevels> lv(n);
@@ -3390,7 +3400,7 @@ int sr_blend_plan_create(sr_ctx *ctx, const sr_tile_rect *h_tiles, int n, int cn
                 T.g_off[i] = (long long)off;
                 if (active) off += (size_t)cn * T.H[i] * T.P[i];
                 T.r_off[i] = (long long)off;
-                if (active) off += (size_t)cn * T.H[i] * T.P[i];
+                if (active && !(P->fused && i == 1)) off += (size_t)cn * T.H[i] * T.P[i];     // fused gather: R_1 lives in LDS only
             }
         }
         P->tile_rows[t] = lv[t].gw[0];
@@ -3439,10 +3449,7 @@ int sr_blend_plan_create(sr_ctx *ctx, const sr_tile_rect *h_tiles, int n, int cn
         D.g2 = T.nl > 2 ? T.g_off[2] : 0; D.r2 = T.nl > 2 ? T.r_off[2] : 0;
         D.w1 = T.nl > 1 ? T.w_off[1] : 0;
     }
-    {
-        const char *env = std::getenv("SR_FUSED_FINAL");
-        P->fused = (cn == 3 || cn == 1) && (env && env[0] == '1');      // opt-in while it is being tuned
-    }
+
     if ((e = hipMalloc((void **)&P->d_luts, sizeof(float) * P->luts.size())) != hipSuccess) return fail(e, "luts");
     {
         // Edge work list: the cells (4 x 2 pixel rectangles of one thread) in which a visit can be a border visit lie
@@ -3536,17 +3543,17 @@ int sr_blend_plan_create(sr_ctx *ctx, const sr_tile_rect *h_tiles, int n, int cn
     if (P->fused) {
         // ---- tables of the fused gather ---------------------------------------------------------------------------------
         const int rows = row_end - row_begin;
-        // host mirror of cell_is_interior (device): a 4 x 4 cell at tile-local (lx0, ly0), nx x ny of it on the strip
+        // host mirror of visit_is_interior<true> (device): a 4 x 2 cell at tile-local (lx0, ly0), nx x ny of it on the strip
         auto cell_interior = [](const TileDev &T, long long lx0, long long ly0, int nx, int ny) {
-            if (nx != 4 || ny != 4 || lx0 < 0 || ly0 < 0 || lx0 + 3 >= T.w || ly0 + 3 >= T.h) return false;
+            if (nx != 4 || ny != 2 || lx0 < 0 || ly0 < 0 || lx0 + 3 >= T.w || ly0 + 1 >= T.h) return false;
             if (T.nl > 1) {
                 const long long r0 = (ly0 - 1) >> 1, c0 = (lx0 - 1) >> 1;
-                return c0 >= 0 && c0 + 3 <= T.W[1] - 1 && r0 >= 0 && r0 + 3 <= T.H[1] - 1;
+                return c0 >= 0 && c0 + 3 <= T.W[1] - 1 && r0 >= 0 && r0 + 2 <= T.H[1] - 1;
             }
             return true;
         };
-        const int enbx = (canvas_w + 255) / 256, enby = (rows + 15) / 16;        // shape 0: 256 x 16
-        const int enbx2 = (canvas_w + 31) / 32, enby2 = (rows + 127) / 128;      // shape 1: 32 x 128
+        const int enbx = (canvas_w + 255) / 256, enby = (rows + FU_E0H - 1) / FU_E0H;     // shape 0: 256 x FU_E0H
+        const int enbx2 = (canvas_w + FU_E1W - 1) / FU_E1W, enby2 = (rows + FU_E1H - 1) / FU_E1H;     // shape 1: FU_E1W x FU_E1H
         std::vector<unsigned char> m0((size_t)std::max(enbx, 1) * std::max(enby, 1), 0), m1((size_t)std::max(enbx2, 1) * std::max(enby2, 1), 0);
         // Every cell with a border visit lies within a few pixels of the edge line of the tile it visits (or on the
         // ragged right / bottom end of the strip): walk the cells of a 24-pixel frame around each tile's outline, test
@@ -3556,15 +3563,15 @@ int sr_blend_plan_create(sr_ctx *ctx, const sr_tile_rect *h_tiles, int n, int cn
             xa = std::max<long long>(xa, 0); xb = std::min<long long>(xb, canvas_w);
             ya = std::max<long long>(ya, row_begin); yb = std::min<long long>(yb, row_end);
             if (xa >= xb || ya >= yb) return;
-            for (long long cy = (ya - row_begin) / 4; cy <= (yb - 1 - row_begin) / 4; ++cy)
+            for (long long cy = (ya - row_begin) / 2; cy <= (yb - 1 - row_begin) / 2; ++cy)
                 for (long long cx = xa / 4; cx <= (xb - 1) / 4; ++cx) {
-                    const long long x0 = cx * 4, y0 = row_begin + cy * 4;
-                    const int nx = (int)std::min<long long>(4, canvas_w - x0), ny = (int)std::min<long long>(4, row_end - y0);
+                    const long long x0 = cx * 4, y0 = row_begin + cy * 2;
+                    const int nx = (int)std::min<long long>(4, canvas_w - x0), ny = (int)std::min<long long>(2, row_end - y0);
                     const long long lx0 = x0 - T.x, ly0 = y0 - T.y;
                     if (lx0 + nx <= 0 || ly0 + ny <= 0 || lx0 >= T.w || ly0 >= T.h) continue;
                     if (cell_interior(T, lx0, ly0, nx, ny)) continue;
-                    if (shape == 0) m0[(size_t)((y0 - row_begin) / 16) * enbx + x0 / 256] = 1;
-                    else m1[(size_t)((y0 - row_begin) / 128) * enbx2 + x0 / 32] = 1;
+                    if (shape == 0) m0[(size_t)((y0 - row_begin) / FU_E0H) * enbx + x0 / 256] = 1;
+                    else m1[(size_t)((y0 - row_begin) / FU_E1H) * enbx2 + x0 / FU_E1W] = 1;
                 }
         };
         const long long F = 24;
@@ -3577,20 +3584,20 @@ int sr_blend_plan_create(sr_ctx *ctx, const sr_tile_rect *h_tiles, int n, int cn
             scan(T, xb - F, ya - F, xb + F, yb + F, 1);
             // the ragged ends of the strip (cells narrower / shorter than 4): border visits of every tile they touch
             if (canvas_w % 4) scan(T, canvas_w - (canvas_w % 4), row_begin, canvas_w, row_end, 1);
-            if (rows % 4) scan(T, 0, row_end - (rows % 4), canvas_w, row_end, 0);
+            if (rows % 2) scan(T, 0, row_end - 1, canvas_w, row_end, 0);
         }
         std::vector<int4> eb;
         for (int by = 0; by < enby; ++by)
             for (int bx = 0; bx < enbx; ++bx)
-                if (m0[(size_t)by * enbx + bx]) eb.push_back(make_int4(bx * 256, row_begin + by * 16, 0, 0));
+                if (m0[(size_t)by * enbx + bx]) eb.push_back(make_int4(bx * 256, row_begin + by * FU_E0H, 0, 0));
         for (int by = 0; by < enby2; ++by)
             for (int bx = 0; bx < enbx2; ++bx)
-                if (m1[(size_t)by * enbx2 + bx]) eb.push_back(make_int4(bx * 32, row_begin + by * 128, 1, 0));
+                if (m1[(size_t)by * enbx2 + bx]) eb.push_back(make_int4(bx * FU_E1W, row_begin + by * FU_E1H, 1, 0));
         std::vector<int> ecand;
         for (auto &e4 : eb) {
             const long long bx0 = e4.x, by0 = e4.y;
-            const long long bx1 = std::min<long long>(bx0 + (e4.z ? 32 : 256), canvas_w);
-            const long long by1 = std::min<long long>(by0 + (e4.z ? 128 : 16), row_end);
+            const long long bx1 = std::min<long long>(bx0 + (e4.z ? FU_E1W : 256), canvas_w);
+            const long long by1 = std::min<long long>(by0 + (e4.z ? FU_E1H : FU_E0H), row_end);
             e4.w = (int)ecand.size();
             for (int t = 0; t < n; ++t) {
                 const TileDev &T = P->tiles[t];
@@ -3824,10 +3831,12 @@ static int blend_gather(sr_blend_plan *P, bool lap, int dtype, void *const *h_d_
         ProfScope ps(ctx, lap ? "final_gather" : "weighted_gather");
         if (lap && P->fused) {
             const int nbx_r = std::max((P->canvas_w + FU_BW - 1) / FU_BW, 1), nby_r = std::max((rows + FU_BH - 1) / FU_BH, 1);
-            dim3 grid((unsigned)(P->n_fedge_blocks + (long long)nbx_r * nby_r)), blk1(256);
+            const int n_edge = P->n_fedge_blocks;
+            const long long n_reg = (long long)nbx_r * nby_r;
+            dim3 grid((unsigned)std::max<long long>(n_edge + n_reg, 1)), blk1(FU_THREADS);
 #define LAUNCH_FUSED(DT, CNV)                                                                                          \
     hipLaunchKernelGGL((k_final_fused<DT, CNV>), grid, blk1, 0, ctx->stream, P->d_fdesc, P->d_fcand_off, P->d_fcand_idx,  \
-                       P->d_fedge_blocks, P->d_fedge_cand, P->n_fedge_blocks, nbx_r, P->d_arena, P->d_luts, d_canvas,   \
+                       P->d_fedge_blocks, P->d_fedge_cand, n_edge, nbx_r, P->d_arena, P->d_luts, d_canvas,   \
                        (long long)canvas_stride, d_canvas_f32, P->canvas_w, P->row_begin, P->row_end)
             if (P->cn == 3) { if (dtype == SR_U8) LAUNCH_FUSED(SRC_U8, 3); else LAUNCH_FUSED(SRC_F32, 3); }
             else            { if (dtype == SR_U8) LAUNCH_FUSED(SRC_U8, 1); else LAUNCH_FUSED(SRC_F32, 1); }
@@ -4497,8 +4506,9 @@ static int assess_impl(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const 
         {
             ProfScope ps(ctx, scope);
             const dim3 grid((unsigned)gbx, (unsigned)gby), block(AM_TX);
+            static const size_t lds_pad = std::getenv("SR_ASSESS_PAD") ? (size_t)atoi(std::getenv("SR_ASSESS_PAD")) : 0;   // experiments: fewer blocks per CU
 #define LAUNCH_ASSESS(CNV, GS, US, SC)                                                                               \
-    hipLaunchKernelGGL((k_assess_march<CNV, GS, US, SC>), grid, block, 0, ctx->stream, d_a, (long long)stride_a, d_b,   \
+    hipLaunchKernelGGL((k_assess_march<CNV, GS, US, SC>), grid, block, lds_pad, ctx->stream, d_a, (long long)stride_a, d_b,   \
                        (long long)stride_b, P, part)
 #define LAUNCH_ASSESS_V(CNV)                                                                                            \
     do {                                                                                                                \

@@ -147,9 +147,10 @@ def test_sharded_blend_rejects_mismatched_arguments(ctx, rng):
                                canvas.ptr, geo.canvas_w * cn)
         with pytest.raises(_native.SrShapeError):                                   # channel count
             comm.blend_sharded(plan, geo.rects, 1, xp.need, xp.owners, ptrs, strides, [0] * n, canvas.ptr, geo.canvas_w * cn)
+        stale = type("StalePlan", (), {"handle": foreign.handle})()         # the raw handle of a plan that is then destroyed
         foreign.close()
         with pytest.raises(ValueError, match="destroyed plan"):
-            comm.blend_sharded(foreign, *args)
+            comm.blend_sharded(stale, *args)
     finally:
         plan.close()
         foreign.close()
