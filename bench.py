@@ -49,21 +49,34 @@ def synthetic_source(w: int = 1080, h: int = 720, seed: int = 20260313, noise_se
     return np.clip(img, 0, 255).astype(np.uint8)
 
 
-def algorithmic_bytes(geo) -> dict:
-    """Bytes each kernel family must move per step (DESIGN.md 'kernels and their rooflines')."""
+def fused_gather_enabled() -> bool:
+    """The library's default: the final gather builds R_1 itself (k_final_fused); SR_FUSED_FINAL=0 selects the unfused pair."""
+    return os.environ.get("SR_FUSED_FINAL", "1")[:1] != "0"
+
+
+def algorithmic_bytes(geo, fused: bool = None) -> dict:
+    """Bytes each kernel family must move per step (DESIGN.md 'kernels and their rooflines').  With the fused gather
+    (round 3) R_1 is never written or read: the collapse chain stops at level 2 and the gather reads G_1, W_1, G_2, R_2."""
     n, m = geo.tile_pixels, geo.canvas_pixels
+    fused = fused_gather_enabled() if fused is None else fused
     s14 = sum(4.0 ** -i for i in range(1, 5))
+    s24 = sum(4.0 ** -i for i in range(2, 5))
     s25 = sum(4.0 ** -i for i in range(2, 6))
-    return {
+    up_all = (34.0 * s14 + 28.0 * 4.0 ** -5) * n                      # G_i, G_i+1/4, R_i+1/4, W_i in; R_i out, levels 5..1
+    out = {
         "tile_extract": 6.0 * n,                                   # 3 B read + 3 B write per tile px
         "down_l0": 6.0 * n,                                        # u8 in (3) + G1 out (12/4)
         "down_l1p": (12.0 * s14 + 12.0 * s25) * n,                 # G1..G4 in, G2..G5 out
-        "up_level": (34.0 * s14 + 28.0 * 4.0 ** -5) * n,           # G_i, G_i+1/4, R_i+1/4, W_i in; R_i out
-        "final_gather": 9.0 * n + 3.0 * m,                         # u8 tile + G1/4 + R1/4 in; u8 canvas out
+        "up_level": (34.0 * s24 + 28.0 * 4.0 ** -5) * n if fused else up_all,       # fused: levels 5..2 only
+        # fused: u8 tile 3 + G_1 12/4 + W_1 4/4 + (G_2 + R_2) 24/16 per tile px in; u8 canvas out
+        "final_gather": (3.0 + 3.0 + 1.0 + 1.5) * n + 3.0 * m if fused else 9.0 * n + 3.0 * m,
         "assess_all": 6.0 * m,                                     # both u8 images once: SSE + 3 SSIM variants (one pass)
         # the reference-shaped model of SURVEY 8(d) (scatter into fp32 accumulators), for comparison
         "_survey_blend_model": 63.30 * n + 19.0 * m,
+        # the unfused design of rounds 1-2 (R_1 written and re-read): the byte count round 2's 60 % target was set on
+        "_r02_blend_design": (6.0 + 12.0 * s14 + 12.0 * s25) * n + up_all + 9.0 * n + 3.0 * m,
     }
+    return out
 
 
 # bench kernel family -> prefix of the rocprofv3 kernel name(s) (template arguments change between builds: matched by prefix)
@@ -71,9 +84,12 @@ ROCPROF_PREFIXES = {"tile_extract": ["k_tile_extract"], "down_l0": ["k_down_marc
                     "up_level": ["k_up_level_blk<"], "final_gather": ["k_final_fast<", "k_final_fused<"],
                     "assess_all": ["k_assess_march<"]}
 BLEND_FAMILIES = ("down_l0", "down_l1p", "up_level", "final_gather")
-# fp64 VALU model of the fused assessment: per pixel (= per thread and row) the march issues 118
-# instructions at the fp64 rate (16 lanes / clock / SIMD: 4 cycles per wave) and 105 at the fp32 rate (2 cycles).
-ASSESS_FP64_INSTR_PER_PX, ASSESS_FP32_INSTR_PER_PX = 118, 105
+# VALU model of the fused assessment: per pixel (= per thread and row) the march issues ~223 VALU instructions
+# (118 of them fp64) and the loader ~14 more (SQ_INSTS_VALU of a launch: 742 M wave-instructions for 200 MP = 237 per
+# 64-pixel row).  On gfx950 a wave's VALU instruction occupies its SIMD for 4 cycles whatever the type (fp64, fp32 and
+# integer alike; only packed fp32 does two lanes' worth): measured on this path, profiles/r03_*.
+ASSESS_VALU_INSTR_PER_PX = 237
+VALU_CYCLES_PER_WAVE_INSTR = 4
 GPU_SIMDS, GPU_CLOCK_HZ = 256 * 4, 2.4e9
 
 
@@ -546,13 +562,14 @@ def run_workload(args, workload: str, steps: int, warmup: int, detailed: bool, d
                     # the kernel that dominates is not HBM-bound: its own roof is fp64 VALU issue (the reference's SSIM is
                     # float64).  floor = pixels x (fp64-rate instr x 4 + fp32-rate instr x 2 cycles per wave of 64) / SIMDs / clock
                     px = geo.canvas_pixels * share
-                    cyc = ASSESS_FP64_INSTR_PER_PX * 4 + ASSESS_FP32_INSTR_PER_PX * 2
+                    cyc = ASSESS_VALU_INSTR_PER_PX * VALU_CYCLES_PER_WAVE_INSTR
                     floor_ms = 1e3 * (px / 64.0) * cyc / GPU_SIMDS / GPU_CLOCK_HZ
                     roofline["valu"] = {"floor_ms": round(floor_ms, 4), "frac": round(floor_ms / per_launch_ms, 4) if per_launch_ms > 0 else None,
                                         "frac_standalone": round(floor_ms / standalone["avg_launch_ms"], 4) if standalone["avg_launch_ms"] > 0 else None,
-                                        "model": f"{ASSESS_FP64_INSTR_PER_PX} fp64-rate (4 cycles / wave) + {ASSESS_FP32_INSTR_PER_PX} fp32-rate "
-                                                 f"(2 cycles / wave) VALU instructions per pixel, {GPU_SIMDS} SIMDs at {GPU_CLOCK_HZ / 1e9:.1f} GHz; "
-                                                 "column halo of the march not counted"}
+                                        "model": f"{ASSESS_VALU_INSTR_PER_PX} VALU instructions per pixel (SQ_INSTS_VALU / pixels x 64) x "
+                                                 f"{VALU_CYCLES_PER_WAVE_INSTR} cycles per wave-instruction, {GPU_SIMDS} SIMDs at "
+                                                 f"{GPU_CLOCK_HZ / 1e9:.1f} GHz: the time the kernel's own instruction stream needs at 100 % VALU "
+                                                 "busy"}
                     roofline["note"] = ("fp64-VALU-bound: `frac` is the HBM fraction the contract asks for, `valu.frac` the fraction "
                                         "of the kernel's own (instruction-issue) roof")
             blend_ms = sum(v["ms_per_step"] for kk, v in kernels.items() if kk in ("weight_down",) + BLEND_FAMILIES)
@@ -563,13 +580,17 @@ def run_workload(args, workload: str, steps: int, warmup: int, detailed: bool, d
                                   "achieved": round(blend_alg / 1e9 / (blend_ms / 1e3), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(blend_alg / 1e9 / (blend_ms / 1e3) / HBM_PEAK_GBS, 4),
                                   "alg_bytes": blend_alg, "ms": round(blend_ms, 4),
+                                  "fused_gather": fused_gather_enabled(),
+                                  "achieved_on_r02_design_bytes": round(alg["_r02_blend_design"] / div / 1e9 / (blend_ms / 1e3), 1),
+                                  "frac_on_r02_design_bytes": round(alg["_r02_blend_design"] / div / 1e9 / (blend_ms / 1e3) / HBM_PEAK_GBS, 4),
                                   "traffic": sum(t["total_2x"] for t in bt) if all(bt) else None,
                                   "traffic_calibrated": sum(t["total"] for t in bt) if all(bt) else None,
                                   "traffic_source": traffic.get("_source"),
                                   "timed_in": "separate sequential pass (standalone kernels, one image at a time)",
-                                  "note": "the Laplacian blend of one image (pyramid down chain, collapse, canvas gather): "
-                                          "north_star's >= 60 % target is on this figure; alg_bytes is this design's (gather) "
-                                          "byte model, smaller than SURVEY 8(d)'s scatter model"}
+                                  "note": "the Laplacian blend of one image (pyramid down chain, collapse, canvas gather); "
+                                          "alg_bytes is THIS design's byte model (fused gather: R_1 never leaves the CU), "
+                                          "smaller than the unfused design of round 2 (frac_on_r02_design_bytes: the same time "
+                                          "priced on that design's 10.18 GB) and than SURVEY 8(d)'s scatter model"}
             gpu_ms = sum(v["ms_per_step"] for v in kernels.values())
             total_alg = sum(alg[kk] for kk in kernels if kk in alg)
             out.update({

@@ -23,9 +23,29 @@ HEADERS = [os.path.join(CSRC, "sr_internal.h"), os.path.join(CSRC, "sr_ctx.h"),
            os.path.join(_ROOT, "include", "sr_hip.h")]
 
 
+def _flags():
+    return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+            # fp-contract off: the fp32 expressions must round exactly like oracle/sr_oracle.c (bit-exact parity).
+            # no SLP: hipcc's automatic v_pk_*_f32 packing costs more register shuffling than it saves here (measured);
+            # where packed fp32 pays (the fused gather) the code spells the pairs out itself.
+            "-ffp-contract=off", "-fno-slp-vectorize", "-fvisibility=hidden", "-DSR_BUILD",
+            "-I", os.path.join(_ROOT, "include"), "-I", CSRC] + os.environ.get("SR_HIPCC_EXTRA", "").split()
+
+
+def _flag_digest_input() -> bytes:
+    # include paths are the same tree at another mount point on the GPU box: only what changes the code generated counts
+    return " ".join(f for f in _flags() if not f.startswith("/") and f != "-I").encode()
+
+
+def sources_present() -> bool:
+    return all(os.path.exists(p) for p in SOURCES + HEADERS)
+
+
 def source_digest() -> str:
-    """sha1 over the sources and headers the library is built from (first 16 hex digits)."""
+    """sha1 over the sources, the headers AND the compile flags the library is built with (first 16 hex digits): an
+    SR_HIPCC_EXTRA experiment can not pass for the default build."""
     h = hashlib.sha1()
+    h.update(_flag_digest_input())
     for p in SOURCES + HEADERS:
         with open(p, "rb") as f:
             h.update(os.path.basename(p).encode())
@@ -33,54 +53,81 @@ def source_digest() -> str:
     return h.hexdigest()[:16]
 
 
+def _object_digest(src: str) -> str:
+    """What one object depends on: its source, every header, the flags."""
+    h = hashlib.sha1()
+    h.update(_flag_digest_input())
+    for p in [src] + HEADERS:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 DIGEST_FILE = os.path.join(_HERE, "libsrhip.digest")
+LOCK_FILE = os.path.join(_HERE, ".build.lock")
 
 
 def _stale() -> bool:
-    """The library is current iff the digest recorded beside it equals the digest of the sources as they are now
-    (file times are not trusted: the tree is copied to the GPU box)."""
+    """The library is current iff the digest recorded beside it equals the digest of the sources (and flags) as they are
+    now (file times are not trusted: the tree is copied to the GPU box).  A tree shipped WITHOUT csrc/ uses the library it
+    came with."""
+    if not sources_present():
+        if os.path.exists(LIB):
+            return False
+        raise FileNotFoundError(f"neither {LIB} nor the sources under {CSRC} are present")
     if not os.path.exists(LIB) or not os.path.exists(DIGEST_FILE):
         return True
     with open(DIGEST_FILE) as f:
         return f.read().strip() != source_digest()
 
 
-def _flags():
-    return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
-            # fp-contract off: the fp32 expressions must round exactly like oracle/sr_oracle.c (bit-exact parity).
-            # no SLP: hipcc's v_pk_*_f32 packing costs more register shuffling than it saves here (measured).
-            "-ffp-contract=off", "-fno-slp-vectorize", "-fvisibility=hidden", "-DSR_BUILD",
-            "-I", os.path.join(_ROOT, "include"), "-I", CSRC] + os.environ.get("SR_HIPCC_EXTRA", "").split()
-
-
 def build_native(force: bool = False, verbose: bool = False) -> str:
+    """Compiles what changed and links libsrhip.so.  Safe under concurrency (every rank of ``bench.py --gpus N`` and the
+    spawn tests call load() at once): one builder at a time under a lock file, objects keyed by a content digest, the
+    library linked to a temporary name and moved into place atomically."""
     if not force and not _stale():
         return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    import fcntl
     os.makedirs(OBJ_DIR, exist_ok=True)
-    digest = source_digest()
-    hdr_t = max(os.path.getmtime(p) for p in HEADERS)
-    jobs, objs = [], []
-    for src in SOURCES:
-        obj = os.path.join(OBJ_DIR, os.path.splitext(os.path.basename(src))[0] + ".o")
-        objs.append(obj)
-        is_host = src.endswith("sr_host.cpp")          # carries the digest: always rebuilt (a second of gcc-class work)
-        if not force and not is_host and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t):
-            continue
-        cmd = [hipcc] + _flags() + (["-x", "hip"] if src.endswith(".hip") else []) + \
-              ([f'-DSR_SOURCE_DIGEST="{digest}"'] if is_host else []) + ["-c", src, "-o", obj]
-        jobs.append(cmd)
+    with open(LOCK_FILE, "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not _stale():                 # another process built it while this one waited
+            return LIB
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        digest = source_digest()
+        jobs, objs = [], []
+        for src in SOURCES:
+            stem = os.path.splitext(os.path.basename(src))[0]
+            obj, tag = os.path.join(OBJ_DIR, stem + ".o"), os.path.join(OBJ_DIR, stem + ".digest")
+            objs.append(obj)
+            is_host = src.endswith("sr_host.cpp")      # carries the library digest: always rebuilt (a second of work)
+            od = _object_digest(src)
+            if not force and not is_host and os.path.exists(obj) and os.path.exists(tag) and open(tag).read().strip() == od:
+                continue
+            cmd = [hipcc] + _flags() + (["-x", "hip"] if src.endswith(".hip") else []) + \
+                  ([f'-DSR_SOURCE_DIGEST="{digest}"'] if is_host else []) + ["-c", src, "-o", obj]
+            jobs.append((cmd, tag, od))
 
-    def run(cmd):
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
+        def run(job):
+            cmd, tag, od = job
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            if tag and os.path.exists(tag):
+                os.remove(tag)                         # an interrupted compile must not leave a matching tag behind
+            subprocess.check_call(cmd)
+            if tag:
+                with open(tag, "w") as f:
+                    f.write(od + "\n")
 
-    with ThreadPoolExecutor(max_workers=min(4, max(len(jobs), 1))) as ex:
-        list(ex.map(run, jobs))
-    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden", "-o", LIB] + objs + ["-lpthread", "-lz", "-ldl"])
-    with open(DIGEST_FILE, "w") as f:
-        f.write(digest + "\n")
+        with ThreadPoolExecutor(max_workers=min(4, max(len(jobs), 1))) as ex:
+            list(ex.map(run, jobs))
+        tmp = LIB + f".tmp.{os.getpid()}"
+        run(([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden", "-o", tmp] + objs + ["-lpthread", "-lz", "-ldl"],
+             None, None))
+        os.replace(tmp, LIB)
+        with open(DIGEST_FILE + ".tmp", "w") as f:
+            f.write(digest + "\n")
+        os.replace(DIGEST_FILE + ".tmp", DIGEST_FILE)
     return LIB
 
 

@@ -213,9 +213,10 @@ def load():
         spec = importlib.util.spec_from_file_location("_sr_build", os.path.join(_HERE, "_build.py"))
         bld = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(bld)
-        if not os.environ.get("SR_LIB_PATH") and bld._stale():                 # missing, or older than a source / header: never run a stale binary silently
+        if not os.environ.get("SR_LIB_PATH"):
             try:
-                bld.build_native()
+                if bld._stale():                       # missing, or not built from these sources / flags: never run a stale binary silently
+                    bld.build_native()
             except Exception as exc:  # noqa: BLE001
                 raise SrNativeError(f"libsrhip.so is missing or older than its sources and could not be rebuilt: {exc}") from exc
         try:
@@ -300,9 +301,15 @@ def strip_tile_rows(rects_xywh, levels: int, canvas_h: int, row_begin: int, row_
     return [(out[2 * i], out[2 * i + 1]) for i in range(n)]
 
 
+_JPEG_EXT = (".jpg", ".jpeg", ".jpe", ".jfif")
+
+
 def write_image(arr: np.ndarray, path: str, threads: int = 0, png_level: int = 3, jpeg_quality: int = 95) -> str:
     """Stage 5 of the pipeline (main.py:399-404) with the native multi-threaded writers: .tif / .tiff -> TIFF-LZW,
-    .png -> PNG (compress_level 3), anything else -> JPEG quality 95.  arr: HxW or HxWxC uint8.  Returns the format."""
+    .png -> PNG (compress_level 3), .jpg / .jpeg / .jpe / .jfif -> JPEG quality 95.  Any other extension goes to Pillow's
+    ``save(path, quality=95)`` -- the reference's own else-branch (main.py:403), which picks the format from the extension
+    (.bmp, .webp, ...) and raises for an unknown one -- never a JPEG stream under another name.  arr: HxW or HxWxC uint8.
+    Returns the format."""
     a = np.ascontiguousarray(arr)
     if a.dtype != np.uint8 or a.ndim not in (2, 3):
         raise ValueError("write_image expects an HxW or HxWxC uint8 array")
@@ -316,10 +323,15 @@ def write_image(arr: np.ndarray, path: str, threads: int = 0, png_level: int = 3
     if low.endswith(".png"):
         check(lib.sr_encode_png(ptr, h, w, cn, w * cn, png_level, p, threads))
         return "PNG"
-    if cn == 4:
-        raise ValueError("cannot write an RGBA image as JPEG")       # Pillow raises OSError here
-    check(lib.sr_encode_jpeg(ptr, h, w, cn, w * cn, jpeg_quality, p, threads))
-    return "JPEG"
+    if low.endswith(_JPEG_EXT):
+        if cn == 4:
+            raise OSError("cannot write mode RGBA as JPEG")             # what Pillow raises (main.py:403 would propagate it)
+        check(lib.sr_encode_jpeg(ptr, h, w, cn, w * cn, jpeg_quality, p, threads))
+        return "JPEG"
+    from PIL import Image
+    img = Image.fromarray(a if cn != 1 else a.reshape(h, w))
+    img.save(path, quality=jpeg_quality)                               # ValueError for an unknown extension, like the reference
+    return (img.format or os.path.splitext(low)[1].lstrip(".")).upper()
 
 
 OWNER_POLICIES = {"balanced": 0, "roundrobin": 1, "locality": 2}

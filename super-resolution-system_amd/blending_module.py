@@ -368,7 +368,10 @@ class BlendingModule:
     @staticmethod
     def _mean_std_table(src_hist: np.ndarray, ref_hist: np.ndarray) -> np.ndarray:
         """_mean_std_matching (:1062-1086) of one channel evaluated for the 256 possible source values: float32
-        (v - src_mean) * (ref_std / (src_std + 1e-6)) + ref_mean, the moments taken exactly from the histograms."""
+        (v - src_mean) * (ref_std / (src_std + 1e-6)) + ref_mean, the moments taken exactly from the histograms.
+        Parity unpinned: the reference takes np.mean / np.std of a float32 HWC array (a running float32 sum per channel),
+        whose rounding error (~1e-4 relative on a multi-megapixel image) moves a mapped value across an integer for a few
+        of the 256 source values: those pixels differ by exactly 1 grey level (tests/test_host_modules.py bounds it)."""
         v = np.arange(256, dtype=np.float64)
 
         def moments(hist):

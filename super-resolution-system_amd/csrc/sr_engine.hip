@@ -4593,10 +4593,15 @@ int sr_assess_resized_u8_async(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a
     {
         ProfScope ps(ctx, "resize_gray");
         if (lds_pitch) {
-            static bool lds_set = false;
-            if (!lds_set) {
-                (void)hipFuncSetAttribute((const void *)k_resize_gray_pair_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-                lds_set = true;
+            {   // once per device (the attribute belongs to the function ON a device), under a lock: contexts of several
+                // devices / threads reach this concurrently
+                static std::mutex mu;
+                static std::set<int> done;
+                std::lock_guard<std::mutex> lk(mu);
+                if (!done.count(ctx->device)) {
+                    HIPCHK(hipFuncSetAttribute((const void *)k_resize_gray_pair_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+                    done.insert(ctx->device);
+                }
             }
             hipLaunchKernelGGL(k_resize_gray_pair_lds, grid, block, (size_t)32 * lds_pitch, ctx->stream, d_a, (long long)stride_a, d_b,
                                (long long)stride_b, h, w, d_xt, d_yt, dst_h, dst_w, gray_shift, ga, gb, (long long)pitch, lds_pitch, part);

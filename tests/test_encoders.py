@@ -83,7 +83,30 @@ def test_writer_errors(tmp_path):
     img = np.zeros((4, 4, 3), np.uint8)
     with pytest.raises(ValueError):
         _native.write_image(img.astype(np.float32), str(tmp_path / "x.png"))
-    with pytest.raises(ValueError):
+    with pytest.raises(OSError):                                      # Pillow: "cannot write mode RGBA as JPEG"
         _native.write_image(np.zeros((4, 4, 4), np.uint8), str(tmp_path / "x.jpg"))
     with pytest.raises(ValueError):
         _native.write_image(img, str(tmp_path / "no" / "such" / "dir" / "x.png"))
+
+
+def test_other_extensions_go_to_pillow(tmp_path):
+    """main.py:403's else-branch is ``img.save(path, quality=95)``: Pillow picks the format from the extension.  The native
+    JPEG writer must only take the JPEG extensions -- a .bmp / .webp path gets that format, an unknown extension raises, an
+    RGBA array written as .jpg raises OSError as Pillow does."""
+    from PIL import Image
+    import _native
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    p = str(tmp_path / "o.bmp")
+    assert _native.write_image(img, p) == "BMP"
+    with Image.open(p) as im:
+        assert im.format == "BMP" and np.array_equal(np.asarray(im), img)
+    for ext in ("jpeg", "jpe", "jfif", "JPG"):
+        q = str(tmp_path / f"o.{ext}")
+        assert _native.write_image(img, q) == "JPEG"
+        with Image.open(q) as im:
+            assert im.format == "JPEG"
+    with pytest.raises(ValueError):
+        _native.write_image(img, str(tmp_path / "o.unknownext"))
+    with pytest.raises(OSError):
+        _native.write_image(np.dstack([img, img[..., :1]]), str(tmp_path / "rgba.jpg"))

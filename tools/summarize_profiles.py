@@ -9,8 +9,8 @@ Rules (round-2 verdict, weak #3):
   * only the run directory named in <collection>/run_id.txt is read -- gpurun MERGES gpurun_out/, so an older collection
     under the same tag may still sit beside the new one; every counter CSV must come from one build (the bench line's
     source digest is recorded);
-  * every kernel is divided by ITS OWN launch count (per launch) and by the number of steps the PMC command ran (per step),
-    never by another kernel's count;
+  * every kernel is divided by ITS OWN launch count (per launch); per step = that x its launches per step, where the steps
+    of the run are the launches of k_tile_extract in the SAME run (one per step by construction, cross-checked);
   * reads are reported twice: `2x` = FETCH_SIZE x 2 as MI355X_MICROARCH.md prescribes for gfx950, `calibrated` = FETCH_SIZE x
     the factor measured on k_tile_extract (a pure copy whose byte count is known);
   * the script FAILS when a bench kernel family's corrected traffic is below 0.9 x its algorithmic bytes (that can only be
@@ -36,7 +36,6 @@ run = f"{src}/{run_id}"
 os.makedirs("profiles", exist_ok=True)
 shutil.copy(f"{run}/kernel_stats.csv", f"profiles/{prefix}_kernel_stats.csv")
 bench = json.load(open(f"{run}/bench.json"))
-pmc_steps = meta["pmc_steps"] + meta["pmc_warmup"]              # every step of the PMC command launches every kernel
 
 
 def counter(name):
@@ -58,6 +57,12 @@ ext = fetch.get("k_tile_extract")
 if not ext:
     sys.exit("k_tile_extract missing from the FETCH_SIZE pass")
 known_read = 3.0 * tile_px                      # k_tile_extract reads exactly the tile pixels once per launch
+# Steps the PMC command ran = launches of k_tile_extract in THIS run (exactly one per step by construction: warm-up, timed
+# steps and the single-image latency pass all go through the tile stage once); cross-checked against the command line.
+pmc_steps = len(ext)
+if pmc_steps < meta["pmc_steps"] + meta["pmc_warmup"] or len(write.get("k_tile_extract", [])) != pmc_steps:
+    sys.exit(f"k_tile_extract ran {pmc_steps} times in the FETCH pass, {len(write.get('k_tile_extract', []))} in the WRITE pass; the "
+             f"command asked for at least {meta['pmc_steps'] + meta['pmc_warmup']} steps")
 cal = known_read / (sum(ext) / len(ext) * 1024.0)
 out = {"format": 2, "run_id": run_id, "build_digest": meta.get("build_digest"),
        "pmc_command_steps": pmc_steps, "fetch_calibration_factor": cal,
