@@ -53,7 +53,7 @@ enum sr_weight_type { SR_W_LINEAR = 0, SR_W_COSINE = 1, SR_W_SIGMOID = 2,
                       SR_W_ONES = 3 };
 /* calculate_ssim branches (quality_assessment_module.py:365-417) */
 enum sr_ssim_mode { SR_SSIM_UNIFORM7 = 0, SR_SSIM_GAUSS11 = 1, SR_SSIM_SIMPLE = 2 };
-enum sr_dtype { SR_U8 = 0, SR_F32 = 1 };
+enum sr_dtype { SR_U8 = 0, SR_F32 = 1, SR_F64 = 2 };   /* SR_F64: sr_ssim_float only */
 
 typedef struct sr_ctx sr_ctx;
 typedef struct sr_blend_plan sr_blend_plan;
@@ -299,6 +299,12 @@ typedef struct sr_merge_tile {
 SR_API int sr_feather_merge(sr_ctx *ctx, const sr_merge_tile *h_tiles, int n, void *const *h_d_tiles,
                             const int64_t *h_strides, int blending, uint8_t *d_canvas,
                             int64_t canvas_stride, int canvas_h, int canvas_w);
+/* the same with the tiles' element type given: SR_U8 (as above) or SR_F32 -- float32 tile data is accumulated as it is
+ * (the reference's astype(float32), tiling_module.py:1104-1109) or goes through cv2.resize's float INTER_LINEAR arithmetic
+ * when its size differs from out_w x out_h.  Strides in bytes. */
+SR_API int sr_feather_merge_dt(sr_ctx *ctx, int dtype, const sr_merge_tile *h_tiles, int n, void *const *h_d_tiles,
+                               const int64_t *h_strides, int blending, uint8_t *d_canvas, int64_t canvas_stride,
+                               int canvas_h, int canvas_w);
 
 /* ---- quality metrics (quality_assessment_module.py:277-417) ---------------------------- */
 /* Sum of squared differences over h rows of rowlen u8 elements -> *h_sse (exact integer).
@@ -323,6 +329,13 @@ SR_API int sr_ssim_u8(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const u
                       int64_t stride_b, int h, int w, int cn, int mode, int gray_shift,
                       double data_range, int row_begin, int row_end, double *h_sum,
                       uint64_t *h_count);
+/* The same three SSIM variants on FLOAT images (the reference passes float arrays with max > 1 on unchanged,
+ * quality_assessment_module.py:169-195,351-417): dtype SR_F32 or SR_F64, cn 1 (gray as it is) or 3 (float32 only: cv2's
+ * float RGB2GRAY, 0.299 R + 0.587 G + 0.114 B in fp32; cv2.cvtColor rejects float64).  float64 arithmetic throughout, like
+ * skimage; a separable reference form, not a tuned kernel.  Strides in bytes. */
+SR_API int sr_ssim_float(sr_ctx *ctx, int dtype, const void *d_a, int64_t stride_a, const void *d_b, int64_t stride_b,
+                         int h, int w, int cn, int mode, double data_range, int row_begin, int row_end, double *h_sum,
+                         uint64_t *h_count);
 SR_API int sr_ssim_u8_async(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uint8_t *d_b,
                             int64_t stride_b, int h, int w, int cn, int mode, int gray_shift,
                             double data_range, int row_begin, int row_end, double *d_sum,

@@ -19,7 +19,7 @@ SR_ERR_INVALID_ARG, SR_ERR_SHAPE, SR_ERR_OOM, SR_ERR_HIP, SR_ERR_COMM, SR_ERR_UN
 PAD_MODES = {"mirror": 0, "replicate": 1, "reflect": 2, "constant": 3}
 WEIGHT_TYPES = {"linear": 0, "cosine": 1, "sigmoid": 2, "ones": 3}
 SSIM_MODES = {"uniform": 0, "gauss": 1, "simple": 2}
-SR_U8, SR_F32 = 0, 1
+SR_U8, SR_F32, SR_F64 = 0, 1, 2
 
 
 class SrNativeError(RuntimeError):
@@ -125,6 +125,7 @@ SIGNATURES = {
     "sr_laplacian_fusion_host": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(TileRect), _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "sr_weighted_fusion_host": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(TileRect), _i, _i, _i, _i, _i, _vp, _vp]),
     "sr_feather_merge": (_i, [_vp, C.POINTER(MergeTile), _i, C.POINTER(_vp), C.POINTER(_i64), _i, _vp, _i64, _i, _i]),
+    "sr_feather_merge_dt": (_i, [_vp, _i, C.POINTER(MergeTile), _i, C.POINTER(_vp), C.POINTER(_i64), _i, _vp, _i64, _i, _i]),
     "sr_sse_u8": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i64, C.POINTER(C.c_uint64)]),
     "sr_sse_u8_async": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i64, _vp]),
     "sr_psnr_from_sse": (_dbl, [C.c_uint64, C.c_uint64, _dbl]),
@@ -133,6 +134,7 @@ SIGNATURES = {
     "sr_sse_f32": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i64, C.POINTER(_dbl)]),
     "sr_weighted_blend_custom": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_i64), C.POINTER(_vp), C.POINTER(_i64), _vp, _i64, _vp]),
     "sr_ssim_u8": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _dbl, _i, _i, C.POINTER(_dbl), C.POINTER(C.c_uint64)]),
+    "sr_ssim_float": (_i, [_vp, _i, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _dbl, _i, _i, C.POINTER(_dbl), C.POINTER(C.c_uint64)]),
     "sr_ssim_u8_async": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _dbl, _i, _i, _vp, C.POINTER(C.c_uint64)]),
     "sr_assess_u8_async": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _dbl, _i, _i, _i, _vp]),
     "sr_assess_u8": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _dbl, _i, _i, _i, C.POINTER(AssessSums)]),
@@ -530,6 +532,14 @@ class Context:
                                   h if row_end is None else row_end, C.byref(s), C.byref(n)))
         return s.value, n.value
 
+    def ssim_float(self, d_a, stride_a, d_b, stride_b, h, w, cn, dtype, mode: str, data_range=255.0, row_begin=0, row_end=None):
+        """sr_ssim_float: (sum, count) of the SSIM map of two float32 (dtype SR_F32) or float64 (SR_F64) images."""
+        s, n = C.c_double(0.0), C.c_uint64(0)
+        check(self.lib.sr_ssim_float(self.handle, int(dtype), C.c_void_p(d_a), stride_a, C.c_void_p(d_b), stride_b, h, w, cn,
+                                     SSIM_MODES[mode], float(data_range), row_begin, h if row_end is None else row_end,
+                                     C.byref(s), C.byref(n)))
+        return s.value, n.value
+
     def ssim_u8_async(self, d_a, stride_a, d_b, stride_b, h, w, cn, mode: str, d_sum: int, gray_shift=15,
                       data_range=255.0, row_begin=0, row_end=None) -> int:
         n = C.c_uint64(0)
@@ -664,17 +674,22 @@ class Context:
 
 
 def _feather_merge_np(self, arrays, descs, output_width: int, output_height: int, blending: bool = True) -> np.ndarray:
-    """TilingModule.merge_tiles on the GPU: arrays are HxWx3 u8 tiles, descs dicts with the sr_merge_tile fields."""
+    """TilingModule.merge_tiles on the GPU: arrays are HxWx3 tiles, ALL uint8 or ALL float32; descs dicts with the
+    sr_merge_tile fields."""
     n = len(arrays)
+    is_f32 = n > 0 and arrays[0].dtype == np.float32
+    if any(a.dtype != (np.float32 if is_f32 else np.uint8) for a in arrays):
+        raise ValueError("feather_merge_np: tiles must be all uint8 or all float32")
+    es = 4 if is_f32 else 1
     bufs = [self.upload(a) for a in arrays]
     mt = (MergeTile * n)(*[MergeTile(*[int(d[k]) for k in ("x", "y", "src_w", "src_h", "out_w", "out_h",
                                                              "ov_t", "ov_b", "ov_l", "ov_r")]) for d in descs])
     ptrs = (C.c_void_p * n)(*[C.c_void_p(b.ptr) for b in bufs])
-    st = (C.c_int64 * n)(*[a.shape[1] * 3 for a in arrays])
+    st = (C.c_int64 * n)(*[a.shape[1] * 3 * es for a in arrays])
     canvas = self.alloc(output_width * output_height * 3)
     try:
-        check(self.lib.sr_feather_merge(self.handle, mt, n, ptrs, st, 1 if blending else 0, C.c_void_p(canvas.ptr),
-                                        output_width * 3, output_height, output_width))
+        check(self.lib.sr_feather_merge_dt(self.handle, SR_F32 if is_f32 else SR_U8, mt, n, ptrs, st, 1 if blending else 0,
+                                           C.c_void_p(canvas.ptr), output_width * 3, output_height, output_width))
         return self.download(canvas.ptr, (output_height, output_width, 3), np.uint8)
     finally:
         self.sync()

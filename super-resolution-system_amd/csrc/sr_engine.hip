@@ -2707,7 +2707,8 @@ static void cubic_table(int n_src, int n_dst, std::vector<CubicTab> &tab)
 // ---------------------------------------------------------------------------------------------
 struct LinTab {
     int ofs;       // left / top source index (clamped)
-    short a0, a1;  // 11-bit coefficients of cv::resize INTER_LINEAR
+    short a0, a1;  // 11-bit coefficients of cv::resize INTER_LINEAR (u8 data)
+    float f;       // the fraction itself (float data: coefficients 1 - f and f)
 };
 
 struct MergeDev {
@@ -2718,6 +2719,7 @@ struct MergeDev {
     double st, sb, sl, sr;  // np.linspace steps: +1/(ov-1) (top/left), -1/(ov-1) (bottom/right); 0 when ov == 1
 };
 
+template <int DT>
 __global__ __launch_bounds__(256) void k_feather_merge(const MergeDev *__restrict__ tiles, const TileSrc *__restrict__ srcs,
                                                        const LinTab *__restrict__ tabs, int n, int blending,
                                                        unsigned char *__restrict__ canvas, long long cstride, int ch,
@@ -2784,7 +2786,7 @@ __global__ __launch_bounds__(256) void k_feather_merge(const MergeDev *__restric
         const long long st = srcs[t].stride;
         const bool whole = lx0 >= 0 && lx0 + 3 < T.out_w && nx == 4;
         unsigned pix[12];
-        if (!T.resize && whole) {
+        if (DT == SRC_U8 && !T.resize && whole) {
             const u3_t q = ld_u3_a1_g(base + (size_t)ly * st + (size_t)lx0 * 3);
             const unsigned wd[3] = {q.x, q.y, q.z};
 #pragma unroll
@@ -2806,7 +2808,26 @@ __global__ __launch_bounds__(256) void k_feather_merge(const MergeDev *__restric
                     w = (float)((double)w * r);
                 }
             }
-            if (T.resize) {
+            if (DT == SRC_F32) {
+                // float tile data (tiling_module.py:1104-1109: astype(float32), or cv2.resize's float INTER_LINEAR path --
+                // rows first, S[x0] * (1 - fx) + S[x1] * fx, then the same between the two rows; parity unpinned)
+                if (T.resize) {
+                    const LinTab X = tabs[T.xtab + lx], Y = tabs[T.ytab + ly];
+                    const int x1 = min(X.ofs + 1, T.src_w - 1), y1 = min(Y.ofs + 1, T.src_h - 1);
+                    const float *r0 = (const float *)(base + (size_t)Y.ofs * st), *r1 = (const float *)(base + (size_t)y1 * st);
+                    const float ax0 = 1.0f - X.f, ax1 = X.f, ay0 = 1.0f - Y.f, ay1 = Y.f;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float s0 = r0[X.ofs * 3 + c] * ax0 + r0[x1 * 3 + c] * ax1;
+                        const float s1 = r1[X.ofs * 3 + c] * ax0 + r1[x1 * 3 + c] * ax1;
+                        acc[k][c] += (s0 * ay0 + s1 * ay1) * w;
+                    }
+                } else {
+                    const float *r0 = (const float *)(base + (size_t)ly * st) + (size_t)lx * 3;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) acc[k][c] += r0[c] * w;
+                }
+            } else if (T.resize) {
                 const LinTab X = tabs[T.xtab + lx], Y = tabs[T.ytab + ly];
                 const int x1 = min(X.ofs + 1, T.src_w - 1), y1 = min(Y.ofs + 1, T.src_h - 1);
                 const unsigned char *r0 = base + (size_t)Y.ofs * st, *r1 = base + (size_t)y1 * st;
@@ -2864,6 +2885,7 @@ static void linear_table(int n_src, int n_dst, std::vector<LinTab> &tab)
         t.ofs = s;
         t.a0 = (short)rintf((1.0f - f) * 2048.0f);
         t.a1 = (short)rintf(f * 2048.0f);
+        t.f = f;
     }
 }
 
@@ -3998,9 +4020,18 @@ int sr_feather_merge(sr_ctx *ctx, const sr_merge_tile *h_tiles, int n, void *con
                      const int64_t *h_strides, int blending, uint8_t *d_canvas, int64_t canvas_stride, int canvas_h,
                      int canvas_w)
 {
+    return sr_feather_merge_dt(ctx, SR_U8, h_tiles, n, h_d_tiles, h_strides, blending, d_canvas, canvas_stride, canvas_h, canvas_w);
+}
+
+int sr_feather_merge_dt(sr_ctx *ctx, int dtype, const sr_merge_tile *h_tiles, int n, void *const *h_d_tiles,
+                        const int64_t *h_strides, int blending, uint8_t *d_canvas, int64_t canvas_stride, int canvas_h,
+                        int canvas_w)
+{
     CTX_ENTER(ctx);
     if (!h_tiles || !h_d_tiles || !h_strides || !d_canvas || n < 0 || canvas_h < 1 || canvas_w < 1)
         return sr_set_error(SR_ERR_INVALID_ARG, "sr_feather_merge: bad arguments");
+    if (dtype != SR_U8 && dtype != SR_F32) return sr_set_error(SR_ERR_INVALID_ARG, "sr_feather_merge: dtype must be SR_U8 or SR_F32");
+    const int es = dtype == SR_U8 ? 1 : 4;
     if (canvas_stride < (int64_t)canvas_w * 3) return sr_set_error(SR_ERR_SHAPE, "sr_feather_merge: canvas stride too small");
     std::vector<MergeDev> md(n);
     std::vector<TileSrc> srcs(n);
@@ -4028,7 +4059,7 @@ int sr_feather_merge(sr_ctx *ctx, const sr_merge_tile *h_tiles, int n, void *con
         D.st = step(D.ov_t, 1.0); D.sb = step(D.ov_b, -1.0); D.sl = step(D.ov_l, 1.0); D.sr = step(D.ov_r, -1.0);
         srcs[t].p = h_d_tiles[t];
         srcs[t].stride = h_strides[t];
-        if (h_strides[t] < (int64_t)m.src_w * 3) return sr_set_error(SR_ERR_SHAPE, "sr_feather_merge: tile %d stride too small", t);
+        if (h_strides[t] < (int64_t)m.src_w * 3 * es) return sr_set_error(SR_ERR_SHAPE, "sr_feather_merge: tile %d stride too small", t);
     }
     const size_t b0 = sizeof(MergeDev) * (size_t)n, b1 = sizeof(TileSrc) * (size_t)n, b2 = sizeof(LinTab) * tabs.size();
     auto al = [](size_t v) { return (v + 255) / 256 * 256; };
@@ -4044,8 +4075,12 @@ int sr_feather_merge(sr_ctx *ctx, const sr_merge_tile *h_tiles, int n, void *con
     {
         ProfScope ps(ctx, "feather_merge");
         dim3 grid((canvas_w + 255) / 256, (canvas_h + 3) / 4), block(64, 4);
-        hipLaunchKernelGGL(k_feather_merge, grid, block, 0, ctx->stream, (const MergeDev *)p0, (const TileSrc *)p1,
-                           (const LinTab *)p2, n, blending ? 1 : 0, d_canvas, (long long)canvas_stride, canvas_h, canvas_w);
+        if (dtype == SR_U8)
+            hipLaunchKernelGGL(k_feather_merge<SRC_U8>, grid, block, 0, ctx->stream, (const MergeDev *)p0, (const TileSrc *)p1,
+                               (const LinTab *)p2, n, blending ? 1 : 0, d_canvas, (long long)canvas_stride, canvas_h, canvas_w);
+        else
+            hipLaunchKernelGGL(k_feather_merge<SRC_F32>, grid, block, 0, ctx->stream, (const MergeDev *)p0, (const TileSrc *)p1,
+                               (const LinTab *)p2, n, blending ? 1 : 0, d_canvas, (long long)canvas_stride, canvas_h, canvas_w);
     }
     return check_launch("feather_merge");
 }
@@ -4417,6 +4452,90 @@ __global__ void k_assess_store(const double *__restrict__ g, const double *__res
 }
 
 // reduce part[n][ncomp] -> returns pointer (inside the two ping-pong buffers) holding ncomp results
+// ---------------------------------------------------------------------------------------------
+// SSIM on FLOAT images.  The reference hands skimage / cv2 whatever _preprocess_image returns: float arrays whose
+// maximum exceeds 1 stay float (quality_assessment_module.py:169-195,351-417).  A plain separable float64 form of
+// oracle_np.ssim, not a tuned kernel (API convenience path; the u8 march above is the hot one):
+//   k_ssimf_gray : gray planes in float64 (float32 RGB: cv2's float cvtColor, ((R*0.299f) + G*0.587f) + B*0.114f in fp32)
+//   k_ssimf_rows : horizontal window sums of x, y, x*x, y*y, x*y (five float64 planes)
+//   k_ssimf_cols : vertical window sums, the SSIM value of the mode, validity, per-block partial sums
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_ssimf_gray(const T *__restrict__ img, long long stride_bytes, int h, int w, int cn,
+                                                    double *__restrict__ out)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const T *row = (const T *)((const char *)img + (size_t)y * stride_bytes);
+    double g;
+    if (cn == 1) g = (double)row[x];
+    else {
+        const float r = (float)row[3 * x], gg = (float)row[3 * x + 1], b = (float)row[3 * x + 2];
+        g = (double)(((r * 0.299f) + gg * 0.587f) + b * 0.114f);
+    }
+    out[(size_t)y * w + x] = g;
+}
+
+struct SsimFParams {
+    int h, w, mode, radius, bmode, crop, row_begin, row_end;
+    double c1, c2, cov_norm;
+    double k[11];
+};
+
+__global__ __launch_bounds__(256) void k_ssimf_rows(const double *__restrict__ ga, const double *__restrict__ gb, SsimFParams P,
+                                                    double *__restrict__ tmp)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= P.w || y >= P.h) return;
+    const size_t plane = (size_t)P.h * P.w;
+    const double *ra = ga + (size_t)y * P.w, *rb = gb + (size_t)y * P.w;
+    double sx = 0.0, sy = 0.0, sxx = 0.0, syy = 0.0, sxy = 0.0;
+    for (int j = 0; j < 2 * P.radius + 1; ++j) {
+        const int xi = border_index(x + j - P.radius, P.w, P.bmode);
+        const double a = ra[xi], b = rb[xi], kj = P.k[j];
+        sx += a * kj;
+        sy += b * kj;
+        sxx += (a * a) * kj;
+        syy += (b * b) * kj;
+        sxy += (a * b) * kj;
+    }
+    const size_t o = (size_t)y * P.w + x;
+    tmp[o] = sx; tmp[plane + o] = sy; tmp[2 * plane + o] = sxx; tmp[3 * plane + o] = syy; tmp[4 * plane + o] = sxy;
+}
+
+__global__ __launch_bounds__(256) void k_ssimf_cols(const double *__restrict__ tmp, SsimFParams P, double *__restrict__ part)
+{
+    __shared__ double ws[4];
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    double v = 0.0;
+    if (x < P.w && y < P.h && y >= max(P.crop, P.row_begin) && y < min(P.h - P.crop, P.row_end) && x >= P.crop && x < P.w - P.crop) {
+        const size_t plane = (size_t)P.h * P.w;
+        double u[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < 2 * P.radius + 1; ++j) {
+            const size_t o = (size_t)border_index(y + j - P.radius, P.h, P.bmode) * P.w + x;
+            const double kj = P.k[j];
+#pragma unroll
+            for (int m = 0; m < 5; ++m) u[m] += tmp[m * plane + o] * kj;
+        }
+        const double ux = u[0], uy = u[1], uxx = u[2], uyy = u[3], uxy = u[4];
+        if (P.mode == SR_SSIM_SIMPLE) {
+            const double m1 = ux * ux, m2 = uy * uy, m12 = ux * uy;
+            const double s1 = uxx - m1, s2 = uyy - m2, s12 = uxy - m12;
+            v = ((2.0 * m12 + P.c1) * (2.0 * s12 + P.c2)) / ((m1 + m2 + P.c1) * (s1 + s2 + P.c2));
+        } else {
+            const double vx = P.cov_norm * (uxx - ux * ux), vy = P.cov_norm * (uyy - uy * uy), vxy = P.cov_norm * (uxy - ux * uy);
+            const double a1 = 2.0 * ux * uy + P.c1, a2 = 2.0 * vxy + P.c2;
+            const double b1 = ux * ux + uy * uy + P.c1, b2 = vx + vy + P.c2;
+            v = (a1 * a2) / (b1 * b2);
+        }
+    }
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const double sred = wave_sum_f64(v);
+    if ((tid & 63) == 0) ws[tid >> 6] = sred;
+    __syncthreads();
+    if (tid == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
 const double *reduce_partials(sr_ctx *ctx, const double *part, long long n, int ncomp, double *buf0, double *buf1)
 {
     const double *src = part;
@@ -4710,6 +4829,72 @@ int sr_ssim_u8(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const uint8_t 
     rc = sr_assess_u8(ctx, d_a, stride_a, d_b, stride_b, h, w, cn, gray_shift, data_range, row_begin, row_end, flag, &sums);
     if (rc) return rc;
     *h_sum = *(const double *)((const char *)&sums + off);
+    return SR_OK;
+}
+
+int sr_ssim_float(sr_ctx *ctx, int dtype, const void *d_a, int64_t stride_a, const void *d_b, int64_t stride_b, int h, int w,
+                  int cn, int mode, double data_range, int row_begin, int row_end, double *h_sum, uint64_t *h_count)
+{
+    CTX_ENTER(ctx);
+    if (!d_a || !d_b || !h_sum || !h_count) return sr_set_error(SR_ERR_INVALID_ARG, "sr_ssim_float: null argument");
+    if (dtype != SR_F32 && dtype != SR_F64) return sr_set_error(SR_ERR_INVALID_ARG, "sr_ssim_float: dtype must be SR_F32 or SR_F64");
+    if (cn != 1 && !(cn == 3 && dtype == SR_F32))
+        return sr_set_error(SR_ERR_INVALID_ARG, "sr_ssim_float: 1 channel, or 3 channels of float32 (cv2.cvtColor rejects float64 RGB)");
+    int flag = 0;
+    size_t off = 0;
+    int rc = ssim_mode_check(h, w, mode, &flag, &off);
+    if (rc) return rc;
+    const int es = dtype == SR_F32 ? 4 : 8;
+    if (stride_a < (int64_t)w * cn * es || stride_b < (int64_t)w * cn * es) return sr_set_error(SR_ERR_SHAPE, "sr_ssim_float: stride smaller than a row");
+    row_begin = std::max(row_begin, 0);
+    row_end = std::min(row_end, h);
+    rc = sr_ssim_count(h, w, mode, row_begin, row_end, h_count);
+    if (rc) return rc;
+    SsimFParams P;
+    memset(&P, 0, sizeof(P));
+    P.h = h; P.w = w; P.mode = mode; P.row_begin = row_begin; P.row_end = row_end;
+    P.c1 = (0.01 * data_range) * (0.01 * data_range);
+    P.c2 = (0.03 * data_range) * (0.03 * data_range);
+    P.cov_norm = 1.0;
+    if (mode == SR_SSIM_UNIFORM7) {
+        P.radius = 3; P.bmode = PAD_REFLECT; P.crop = 3; P.cov_norm = 49.0 / 48.0;
+        for (int j = 0; j < 7; ++j) P.k[j] = 1.0 / 7.0;
+    } else {
+        double k6[6];
+        gauss_taps(k6);                                  // scipy's and cv2's normalised 11-tap kernels coincide
+        P.radius = 5;
+        for (int j = 0; j <= 5; ++j) P.k[5 + j] = P.k[5 - j] = k6[j];
+        if (mode == SR_SSIM_GAUSS11) { P.bmode = PAD_REFLECT; P.crop = 5; }
+        else { P.bmode = PAD_MIRROR; P.crop = 0; P.c1 = (0.01 * 255.0) * (0.01 * 255.0); P.c2 = (0.03 * 255.0) * (0.03 * 255.0); }
+    }
+    const size_t plane = (size_t)h * w;
+    const dim3 block(64, 4), grid((unsigned)((w + 63) / 64), (unsigned)((h + 3) / 4));
+    const size_t nblk = (size_t)grid.x * grid.y;
+    double *buf = nullptr;
+    {
+        hipError_t e = hipMalloc((void **)&buf, (7 * plane + nblk + 2 * (nblk / 1024 + 2)) * sizeof(double));
+        if (e != hipSuccess) return sr_set_error(e == hipErrorOutOfMemory ? SR_ERR_OOM : SR_ERR_HIP, "sr_ssim_float: %s", hipGetErrorString(e));
+    }
+    double *ga = buf, *gb = buf + plane, *tmp = buf + 2 * plane, *part = buf + 7 * plane, *b0 = part + nblk, *b1 = b0 + nblk / 1024 + 2;
+    {
+        ProfScope ps(ctx, "ssim_float");
+        if (dtype == SR_F32) {
+            hipLaunchKernelGGL(k_ssimf_gray<float>, grid, block, 0, ctx->stream, (const float *)d_a, (long long)stride_a, h, w, cn, ga);
+            hipLaunchKernelGGL(k_ssimf_gray<float>, grid, block, 0, ctx->stream, (const float *)d_b, (long long)stride_b, h, w, cn, gb);
+        } else {
+            hipLaunchKernelGGL(k_ssimf_gray<double>, grid, block, 0, ctx->stream, (const double *)d_a, (long long)stride_a, h, w, cn, ga);
+            hipLaunchKernelGGL(k_ssimf_gray<double>, grid, block, 0, ctx->stream, (const double *)d_b, (long long)stride_b, h, w, cn, gb);
+        }
+        hipLaunchKernelGGL(k_ssimf_rows, grid, block, 0, ctx->stream, (const double *)ga, (const double *)gb, P, tmp);
+        hipLaunchKernelGGL(k_ssimf_cols, grid, block, 0, ctx->stream, (const double *)tmp, P, part);
+    }
+    const double *res = reduce_partials(ctx, part, (long long)nblk, 1, b0, b1);
+    rc = check_launch("ssim_float");
+    hipError_t e = hipMemcpyAsync(h_sum, res, sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t es2 = stream_sync(ctx);
+    (void)hipFree(buf);
+    if (rc) return rc;
+    if (e != hipSuccess || es2 != hipSuccess) return sr_set_error(SR_ERR_HIP, "sr_ssim_float: %s", hipGetErrorString(e != hipSuccess ? e : es2));
     return SR_OK;
 }
 

@@ -243,8 +243,42 @@ class QualityAssessmentModule:
         finally:
             da.free(); db.free()
 
+    def _ssim_float(self, p1: np.ndarray, p2: np.ndarray, multiscale: bool, data_range: float) -> float:
+        """Images that stay non-u8 after _preprocess_image (float arrays with max > 1, wider integers): the reference hands
+        them on as they are -- a float32 RGB pair through cv2's float RGB2GRAY, a 2-D pair straight to skimage, which
+        computes in float64 (quality_assessment_module.py:351-417).  Runs on sr_ssim_float; float64 RGB raises like
+        cv2.cvtColor does."""
+        a, b = self._crop_pair(np.asarray(p1), np.asarray(p2))
+        if a.ndim != b.ndim or (a.ndim == 3 and a.shape[2] != b.shape[2]):
+            raise ValueError(f"calculate_ssim: images have different channel layouts {a.shape} vs {b.shape}")
+        if a.ndim == 3:
+            if a.shape[2] != 3:
+                raise ValueError("calculate_ssim: colour images must have 3 channels (cv2.COLOR_RGB2GRAY)")
+            if a.dtype not in (np.uint8, np.float32) or b.dtype not in (np.uint8, np.float32):
+                raise ValueError("calculate_ssim: cv2.cvtColor(RGB2GRAY) supports 8-bit, 16-bit and float32 images only "
+                                 f"(got {a.dtype} / {b.dtype}); 16-bit RGB is not on the HIP path")
+            dt, code = np.float32, _native.SR_F32          # a u8 partner of a float32 image is converted (values exact)
+        else:
+            dt, code = (np.float32, _native.SR_F32) if (a.dtype == np.float32 and b.dtype == np.float32) else (np.float64, _native.SR_F64)
+        a = np.ascontiguousarray(a, dtype=dt)
+        b = np.ascontiguousarray(b, dtype=dt)
+        h, w = a.shape[:2]
+        cn = 3 if a.ndim == 3 else 1
+        mode = "simple" if self.ssim_branch == 'B' else ("gauss" if multiscale else "uniform")
+        ctx = self._ctx()
+        da, db = ctx.upload(a), ctx.upload(b)
+        try:
+            es = a.dtype.itemsize
+            s, n = ctx.ssim_float(da.ptr, w * cn * es, db.ptr, w * cn * es, h, w, cn, code, mode, data_range)
+            return float(s / n)
+        finally:
+            da.free(); db.free()
+
     def calculate_ssim(self, img1: np.ndarray, img2: np.ndarray, multiscale: bool = True,
                        data_range: float = 255.0) -> float:
+        p1, p2 = self._preprocess_image(img1), self._preprocess_image(img2)
+        if np.asarray(p1).dtype != np.uint8 or np.asarray(p2).dtype != np.uint8:
+            return self._ssim_float(p1, p2, multiscale, data_range)
         a, b = self._pair(img1, img2, "calculate_ssim")
         if a.ndim == 3 and a.shape[2] != 3:
             raise ValueError("calculate_ssim: colour images must have 3 channels (cv2.COLOR_RGB2GRAY)")

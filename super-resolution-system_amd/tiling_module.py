@@ -328,11 +328,24 @@ class TilingModule:
             return np.zeros((output_height, output_width, 3), dtype=np.uint8)
         s = self.output_scale
         descs, arrays = [], []
+        # The reference casts whatever dtype the tiles carry (tiling_module.py:1104-1109: astype(float32), or cv2.resize
+        # in the data's own type).  uint8 tiles take the u8 path; anything else is taken as float32 -- exact for the
+        # no-resize branch of every dtype float32 represents, cv2's float INTER_LINEAR arithmetic where sizes differ
+        # (a float64 or 16-bit tile that needs resizing would go through cv2's double / fixed-point path instead:
+        # refused rather than approximated).
+        all_u8 = all(np.asarray(t.data).dtype == np.uint8 for t in live)
         for t in live:
             m = t.metadata
-            data = np.ascontiguousarray(t.data)
-            if data.dtype != np.uint8:
-                raise NotImplementedError("merge_tiles: only uint8 tile data is on the HIP path")
+            data = np.asarray(t.data)
+            if not all_u8:
+                resized = data.shape[0] != m.output_h or data.shape[1] != m.output_w
+                if resized and data.dtype not in (np.float32, np.uint8):
+                    raise NotImplementedError(f"merge_tiles: {data.dtype} tile data that needs resizing is not on the HIP path "
+                                              "(cv2.resize would run its own arithmetic for that type)")
+                if resized and data.dtype == np.uint8:
+                    raise NotImplementedError("merge_tiles: uint8 tiles that need resizing mixed with float tiles")
+                data = data.astype(np.float32)
+            data = np.ascontiguousarray(data)
             if data.ndim != 3 or data.shape[2] != 3:
                 raise ValueError("merge_tiles expects HxWx3 tiles")
             h, w = data.shape[:2]
