@@ -1050,6 +1050,22 @@ __device__ __forceinline__ void div_shared(const float (&a)[CN], float w, float 
 {
     float r = __builtin_amdgcn_rcpf(w);
     r = fmaf(fmaf(-w, r, 1.0f), r, r);
+    if (CN == 3) {
+        // channels 0 and 1 as one packed pair (v_pk_mul / v_pk_fma: the same fma chain per element), channel 2 scalar
+        f2_t a01, nw, rr;
+        a01.x = a[0]; a01.y = a[1];
+        nw.x = nw.y = -w;
+        rr.x = rr.y = r;
+        f2_t t = a01 * rr;
+        t = __builtin_elementwise_fma(__builtin_elementwise_fma(nw, t, a01), rr, t);
+        t = __builtin_elementwise_fma(__builtin_elementwise_fma(nw, t, a01), rr, t);
+        q[0] = t.x;
+        q[1] = t.y;
+        float t2 = a[2] * r;
+        t2 = fmaf(fmaf(-w, t2, a[2]), r, t2);
+        q[2] = fmaf(fmaf(-w, t2, a[2]), r, t2);
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < CN; ++c) {
         float t = a[c] * r;
