@@ -386,10 +386,12 @@ SR_API int sr_resize_cubic_window_u8(sr_ctx *ctx, const uint8_t *d_src, int64_t 
  * sr_histogram_u8: per-channel 256-bin histogram (np.histogram(ch, 256, [0, 256]) of u8 data), h_hist = cn x 256 counts.
  * The matching itself is 256-entry bookkeeping on the host (CDFs in float64, argmin; or the mean / std affine map of
  * _mean_std_matching) and arrives here as a per-channel table h_glut[c][v] = corrected float value of source value v.
- * sr_color_correct_u8: out = astype(u8)(clip(corrected, 0, 255)) with corrected = h_glut[c][img]; with local_filter != 0
+ * sr_color_correct_u8: out = astype(u8)(clip(corrected, 0, 255)) with corrected = h_glut[c][img]; with local_filter == 1
  * corrected goes through _simple_guided_filter(guide = corrected, src = img, radius, eps) first (:1110-1146: five
- * cv2.blur((radius, radius)) box means -- anchor radius / 2, REFLECT_101 -- and fp32 element-wise algebra; the
- * cv2.ximgproc.guidedFilter branch of :1098-1105 is not built).  radius 1..16. */
+ * cv2.blur((radius, radius)) box means -- anchor radius / 2, REFLECT_101 -- and fp32 element-wise algebra); with
+ * local_filter == 2 through the cv2.ximgproc.guidedFilter branch of :1108-1111 instead ((2 radius + 1)^2 window,
+ * BORDER_REFLECT, colour guide: per-pixel 3 x 3 covariance inverse; 1 or 3 channels; restated, parity unpinned).
+ * radius 1..16. */
 SR_API int sr_histogram_u8(sr_ctx *ctx, const uint8_t *d_img, int64_t stride, int h, int w, int cn, uint64_t *h_hist);
 SR_API int sr_color_correct_u8(sr_ctx *ctx, const uint8_t *d_img, int64_t stride, int h, int w, int cn,
                                const float *h_glut, int local_filter, int radius, float eps, uint8_t *d_out,

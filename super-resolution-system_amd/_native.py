@@ -591,11 +591,11 @@ class Context:
                                        out.ctypes.data_as(C.POINTER(C.c_uint64))))
         return out.astype(np.int64)
 
-    def color_correct_u8(self, d_img, stride, h, w, cn, glut: np.ndarray, local_filter: bool, radius: int, eps: float,
+    def color_correct_u8(self, d_img, stride, h, w, cn, glut: np.ndarray, local_filter: int, radius: int, eps: float,
                          d_out, out_stride):
         g = np.ascontiguousarray(glut, dtype=np.float32).reshape(cn, 256)
         check(self.lib.sr_color_correct_u8(self.handle, C.c_void_p(d_img), int(stride), int(h), int(w), int(cn),
-                                           g.ctypes.data_as(C.POINTER(C.c_float)), 1 if local_filter else 0, int(radius),
+                                           g.ctypes.data_as(C.POINTER(C.c_float)), int(local_filter), int(radius),
                                            C.c_float(eps), C.c_void_p(d_out), int(out_stride)))
 
     def rgb2gray_u8(self, d_rgb, stride, h, w, d_gray, gray_stride, gray_shift=15):

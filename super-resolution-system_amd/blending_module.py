@@ -17,6 +17,7 @@ weight is 0, saturates; ``overlap_map`` is accepted and ignored (blending_module
 from __future__ import annotations
 
 import logging
+import os
 from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass, field
 from enum import Enum
@@ -105,8 +106,16 @@ class BlendingModule:
     threads (ParallelBlender does); device work is serialised per context inside the library."""
 
     def __init__(self, method: str = 'laplacian', num_levels: int = 6, ssim_threshold: float = 0.95,
-                 use_cuda: bool = False, device: int = 0):
+                 use_cuda: bool = False, device: int = 0, guided_filter: Optional[str] = None):
         self.method = FusionMethod(method)          # ValueError on an unknown name, as the reference
+        # Which branch of _guided_filter (blending_module.py:1108-1114) color_correction takes: the reference tries
+        # cv2.ximgproc.guidedFilter and falls back to its own _simple_guided_filter when opencv-contrib is absent.
+        # 'simple' (default: the branch the reference spells out) or 'ximgproc' (restated, parity unpinned);
+        # SR_GUIDED_FILTER overrides the default.
+        gf = guided_filter or os.environ.get("SR_GUIDED_FILTER", "simple")
+        if gf not in ("simple", "ximgproc"):
+            raise ValueError(f"guided_filter must be 'simple' or 'ximgproc', got {gf!r}")
+        self.guided_filter = gf
         self.num_levels = num_levels
         self.ssim_threshold = ssim_threshold
         # the reference's flag selects cv2.cuda; here every path is the HIP path
@@ -415,7 +424,8 @@ class BlendingModule:
                     glut[c] = self._mean_std_table(sh[c], rh[c])
                 else:
                     glut[c] = np.arange(256, dtype=np.float32)
-            ctx.color_correct_u8(d_img.ptr, w * cn, h, w, cn, glut, bool(local_filter), 8, 0.01, out.ptr, w * cn)
+            mode = 0 if not local_filter else (2 if self.guided_filter == "ximgproc" else 1)
+            ctx.color_correct_u8(d_img.ptr, w * cn, h, w, cn, glut, mode, 8, 0.01, out.ptr, w * cn)
             return ctx.download(out.ptr, img.shape, np.uint8)
         finally:
             ctx.sync()

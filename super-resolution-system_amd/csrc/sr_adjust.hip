@@ -394,6 +394,127 @@ __global__ __launch_bounds__(256) void k_cc_apply8(const unsigned char *__restri
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The OTHER branch of BlendingModule._guided_filter (blending_module.py:1108-1111): cv2.ximgproc.guidedFilter(guide, src,
+// radius, eps), which is what runs when opencv-contrib is installed (requirements.txt:6).  He et al.'s guided filter with a
+// (2 r + 1)^2 box window and, for a 3-channel guide, the colour form: per pixel the 3 x 3 covariance of the guide (+ eps on
+// the diagonal) is inverted and every source channel gets a 3-vector a and an offset b.  PARITY UNPINNED: restated from the
+// published algorithm and OpenCV-contrib's guided_filter.cpp as remembered (float32 planes, box means through
+// cv::boxFilter with float64 sums, BORDER_REFLECT, cofactor inverse); oracle_np.guided_filter_ximgproc spells out the same
+// expression order and is what the GPU result is compared with.  A correctness-first layout -- one launch per box mean over
+// planar float32 temporaries -- not a tuned kernel; the default stays the _simple_guided_filter branch (sr_color_correct_u8
+// local_filter = 1).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int gf_reflect(int p, int n)           // BORDER_REFLECT: fedcba|abcdefgh|hgfedcb
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p - 1 : 2 * n - 1 - p;
+    return p;
+}
+
+// I_c = glut[c][v], p_c = v as float32 planes: planes[c] = I_c, planes[cn + c] = p_c
+__global__ __launch_bounds__(256) void k_gf_planes(const unsigned char *__restrict__ img, long long stride, int h, int w, int cn,
+                                                   const float *__restrict__ glut, float *__restrict__ planes)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const size_t plane = (size_t)h * w, o = (size_t)y * w + x;
+    for (int c = 0; c < cn; ++c) {
+        const int v = img[(size_t)y * stride + (size_t)x * cn + c];
+        planes[c * plane + o] = glut[c * 256 + v];
+        planes[(cn + c) * plane + o] = (float)v;
+    }
+}
+
+// dst = boxFilter(A * B  or  A, (R, R), normalize, BORDER_REFLECT), sums in float64: each window row left to right, then the
+// row sums top to bottom (cv::boxFilter's order), mean = (float)(sum * scale).  Block = 64 x 16 outputs.
+__global__ __launch_bounds__(256) void k_gf_box(const float *__restrict__ A, const float *__restrict__ B, int h, int w, int R,
+                                                double scale, float *__restrict__ dst)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int PH = CC_TH + R - 1, PW = CC_TW + R - 1, anchor = R / 2;
+    float *pt = (float *)smem;                                            // [PH][PW]
+    double *hs = (double *)(smem + (((size_t)PH * PW * sizeof(float) + 15) & ~(size_t)15));   // [PH][TW]
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * CC_TW, y0 = blockIdx.y * CC_TH;
+    for (int e = tid; e < PH * PW; e += 256) {
+        const int py = e / PW, px = e - py * PW;
+        const size_t o = (size_t)gf_reflect(y0 + py - anchor, h) * w + gf_reflect(x0 + px - anchor, w);
+        pt[e] = B ? A[o] * B[o] : A[o];
+    }
+    __syncthreads();
+    for (int e = tid; e < PH * CC_TW; e += 256) {
+        const int py = e / CC_TW, ox = e - py * CC_TW;
+        double sacc = 0.0;
+        for (int k = 0; k < R; ++k) sacc += (double)pt[py * PW + ox + k];
+        hs[e] = sacc;
+    }
+    __syncthreads();
+    for (int e = tid; e < CC_TH * CC_TW; e += 256) {
+        const int oy = e / CC_TW, ox = e - oy * CC_TW;
+        const int y = y0 + oy, x = x0 + ox;
+        if (y >= h || x >= w) continue;
+        double t = 0.0;
+        for (int k = 0; k < R; ++k) t += hs[(size_t)(oy + k) * CC_TW + ox];
+        dst[(size_t)y * w + x] = (float)(t * scale);
+    }
+}
+
+// per pixel: the linear coefficients.  means: [0..2] mI, [3..8] mII (00 01 02 11 12 22), [9..11] mp, [12..20] mIp (c * 3 + i).
+// out: [c * 3 + i] a_ci, [9 + c] b_c.  cn == 1: means [0] mI, [1] mII, [2] mp, [3] mIp -> out [0] a, [1] b.
+__global__ __launch_bounds__(256) void k_gf_coeff(const float *__restrict__ means, size_t plane, long long n, int cn, float eps,
+                                                  float *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    auto M = [&](int m) { return means[(size_t)m * plane + i]; };
+    if (cn == 1) {
+        const float mI = M(0), mp = M(2);
+        const float var = (M(1) - mI * mI) + eps, cov = M(3) - mI * mp;
+        const float a = cov / var;
+        out[i] = a;
+        out[plane + i] = mp - a * mI;
+        return;
+    }
+    const float m0 = M(0), m1 = M(1), m2 = M(2);
+    const float c00 = (M(3) - m0 * m0) + eps, c01 = M(4) - m0 * m1, c02 = M(5) - m0 * m2;
+    const float c11 = (M(6) - m1 * m1) + eps, c12 = M(7) - m1 * m2, c22 = (M(8) - m2 * m2) + eps;
+    const float A00 = c11 * c22 - c12 * c12, A01 = c02 * c12 - c01 * c22, A02 = c01 * c12 - c02 * c11;
+    const float A11 = c00 * c22 - c02 * c02, A12 = c01 * c02 - c00 * c12, A22 = c00 * c11 - c01 * c01;
+    const float det = (c00 * A00 + c01 * A01) + c02 * A02;
+    const float i00 = A00 / det, i01 = A01 / det, i02 = A02 / det, i11 = A11 / det, i12 = A12 / det, i22 = A22 / det;
+    for (int c = 0; c < 3; ++c) {
+        const float mp = M(9 + c);
+        const float v0 = M(12 + c * 3) - m0 * mp, v1 = M(13 + c * 3) - m1 * mp, v2 = M(14 + c * 3) - m2 * mp;
+        const float a0 = (i00 * v0 + i01 * v1) + i02 * v2;
+        const float a1 = (i01 * v0 + i11 * v1) + i12 * v2;
+        const float a2 = (i02 * v0 + i12 * v1) + i22 * v2;
+        out[(size_t)(c * 3) * plane + i] = a0;
+        out[(size_t)(c * 3 + 1) * plane + i] = a1;
+        out[(size_t)(c * 3 + 2) * plane + i] = a2;
+        out[(size_t)(9 + c) * plane + i] = mp - ((a0 * m0 + a1 * m1) + a2 * m2);
+    }
+}
+
+// q_c = (mean_a_c . I) + mean_b_c -> clip -> truncate (blending_module.py:1017)
+__global__ __launch_bounds__(256) void k_gf_out(const float *__restrict__ planes, const float *__restrict__ mab, size_t plane, int h,
+                                                int w, int cn, unsigned char *__restrict__ out, long long ostride)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const size_t o = (size_t)y * w + x;
+    for (int c = 0; c < cn; ++c) {
+        float r;
+        if (cn == 1) r = mab[o] * planes[o] + mab[plane + o];
+        else
+            r = ((mab[(size_t)(c * 3) * plane + o] * planes[o] + mab[(size_t)(c * 3 + 1) * plane + o] * planes[plane + o]) +
+                 mab[(size_t)(c * 3 + 2) * plane + o] * planes[2 * plane + o]) + mab[(size_t)(9 + c) * plane + o];
+        const float cl = r < 0.0f ? 0.0f : (r > 255.0f ? 255.0f : r);
+        out[(size_t)y * ostride + (size_t)x * cn + c] = (unsigned char)cl;
+    }
+}
+
 // no local filter: out = u8(clip(glut[c][v], 0, 255))
 __global__ __launch_bounds__(256) void k_cc_map(const unsigned char *__restrict__ img, long long stride, int h, long long rowlen,
                                                 int cn, const float *__restrict__ glut, unsigned char *__restrict__ out,
@@ -501,6 +622,58 @@ int sr_color_correct_u8(sr_ctx *ctx, const uint8_t *d_img, int64_t stride, int h
         hipLaunchKernelGGL(k_cc_map, grid, dim3(256), 0, ctx->stream, d_img, (long long)stride, h, rowlen, cn, (const float *)d_glut,
                            d_out, (long long)out_stride);
         return check_launch("color_map");
+    }
+    if (local_filter == 2) {
+        // cv2.ximgproc.guidedFilter semantics (parity unpinned; see k_gf_*): window 2 r + 1, colour guide
+        if (cn != 1 && cn != 3) return sr_set_error(SR_ERR_INVALID_ARG, "sr_color_correct_u8: the ximgproc guided filter takes 1 or 3 channels");
+        const int R = 2 * radius + 1, nmean = cn == 3 ? 21 : 4, nab = cn == 3 ? 12 : 2;
+        const size_t plane = (size_t)h * w;
+        float *buf = nullptr;
+        {
+            hipError_t e = hipMalloc((void **)&buf, (size_t)(2 * cn + nmean + 2 * nab) * plane * sizeof(float));
+            if (e != hipSuccess)
+                return sr_set_error(e == hipErrorOutOfMemory ? SR_ERR_OOM : SR_ERR_HIP, "sr_color_correct_u8: %s", hipGetErrorString(e));
+        }
+        float *planes = buf, *means = planes + 2 * cn * plane, *ab = means + (size_t)nmean * plane, *mab = ab + (size_t)nab * plane;
+        const int PH = CC_TH + R - 1, PW = CC_TW + R - 1;
+        const size_t lds = ((((size_t)PH * PW * sizeof(float)) + 15) & ~(size_t)15) + (size_t)PH * CC_TW * sizeof(double);
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_gf_box, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const double scale = 1.0 / ((double)R * (double)R);
+        const dim3 g4((w + 63) / 64, (h + 3) / 4), b4(64, 4), gt((w + CC_TW - 1) / CC_TW, (h + CC_TH - 1) / CC_TH);
+        {
+            ProfScope ps(ctx, "guided_ximgproc");
+            hipLaunchKernelGGL(k_gf_planes, g4, b4, 0, ctx->stream, d_img, (long long)stride, h, w, cn, (const float *)d_glut, planes);
+            auto box = [&](const float *A, const float *B, float *dst) {
+                hipLaunchKernelGGL(k_gf_box, gt, dim3(256), lds, ctx->stream, A, B, h, w, R, scale, dst);
+            };
+            auto I = [&](int c) { return planes + (size_t)c * plane; };
+            auto Pp = [&](int c) { return planes + (size_t)(cn + c) * plane; };
+            int m = 0;
+            if (cn == 1) {
+                box(I(0), nullptr, means);
+                box(I(0), I(0), means + plane);
+                box(Pp(0), nullptr, means + 2 * plane);
+                box(I(0), Pp(0), means + 3 * plane);
+            } else {
+                for (int c = 0; c < 3; ++c) box(I(c), nullptr, means + (size_t)(m++) * plane);
+                for (int a = 0; a < 3; ++a)
+                    for (int b2 = a; b2 < 3; ++b2) box(I(a), I(b2), means + (size_t)(m++) * plane);
+                for (int c = 0; c < 3; ++c) box(Pp(c), nullptr, means + (size_t)(m++) * plane);
+                for (int c = 0; c < 3; ++c)
+                    for (int a = 0; a < 3; ++a) box(I(a), Pp(c), means + (size_t)(m++) * plane);
+            }
+            hipLaunchKernelGGL(k_gf_coeff, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, ctx->stream, (const float *)means, plane,
+                               (long long)plane, cn, eps, ab);
+            for (int k = 0; k < nab; ++k) box(ab + (size_t)k * plane, nullptr, mab + (size_t)k * plane);
+            hipLaunchKernelGGL(k_gf_out, g4, b4, 0, ctx->stream, (const float *)planes, (const float *)mab, plane, h, w, cn, d_out,
+                               (long long)out_stride);
+        }
+        int rc2 = check_launch("guided_ximgproc");
+        hipError_t es2 = stream_sync(ctx);
+        (void)hipFree(buf);
+        if (rc2) return rc2;
+        if (es2 != hipSuccess) return sr_set_error(SR_ERR_HIP, "sr_color_correct_u8: %s", hipGetErrorString(es2));
+        return SR_OK;
     }
     // a / b planes (8 bytes per sample): an allocation of their own, released when the call is done
     float *d_a = nullptr;

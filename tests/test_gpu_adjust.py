@@ -83,3 +83,28 @@ def test_mixed_channel_tiles_raise(rng):
     a, b = _scene(rng, 32, 32, 3), _scene(rng, 32, 32, 4)
     with pytest.raises(ValueError):
         bm.laplacian_fusion([TileInfo(a, 0, 0, 0, 0), TileInfo(b, 16, 0, 0, 1)])
+
+
+@pytest.mark.parametrize("method", ["histogram", "mean_std"])
+def test_color_correction_ximgproc_branch(rng, method):
+    """The try-branch of _guided_filter (blending_module.py:1108-1111: cv2.ximgproc.guidedFilter, what runs with
+    opencv-contrib installed), selected with guided_filter='ximgproc': (2 r + 1)^2 window, colour guide with the per-pixel
+    3 x 3 covariance inverse.  Bit-exact vs oracle_np.guided_filter_ximgproc, which restates it -- PARITY UNPINNED (no cv2
+    here, the reference holds no fixture).  Also: gray images, an image smaller than the 17 x 17 window, and that the two
+    branches really differ."""
+    from blending_module import BlendingModule
+    bx = BlendingModule(guided_filter="ximgproc")
+    img = _scene(rng, 120, 171)
+    ref = np.clip(_scene(rng, 90, 77).astype(np.int16) // 2 + 60, 0, 255).astype(np.uint8)
+    got = bx.color_correction(img, ref, method=method)
+    want = onp.color_correction(img, ref, method=method, guided="ximgproc")
+    assert got.dtype == np.uint8 and got.shape == img.shape
+    assert np.array_equal(got, want), int((got != want).sum())
+    assert not np.array_equal(got, BlendingModule().color_correction(img, ref, method=method))
+    g, r = _scene(rng, 41, 99, cn=1)[..., 0], _scene(rng, 20, 20, cn=1)[..., 0]
+    assert np.array_equal(bx.color_correction(g, r, method=method), onp.color_correction(g, r, method=method, guided="ximgproc"))
+    tiny = _scene(rng, 6, 9)
+    assert np.array_equal(bx.color_correction(tiny, tiny[::-1].copy(), method=method),
+                          onp.color_correction(tiny, tiny[::-1].copy(), method=method, guided="ximgproc"))
+    with pytest.raises(ValueError):
+        BlendingModule(guided_filter="bilateral")
