@@ -4448,6 +4448,100 @@ __global__ __launch_bounds__(256) void k_resize_gray_pair_lds(const unsigned cha
     if (tid == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
 }
 
+// The same sampler for gentle down-sampling (scale above ~0.25: the four tap rows of consecutive destination rows
+// overlap): a block owns 64 x 16 destination pixels and stages every SOURCE row between its first and last tap ONCE
+// (about 43 rows per image at x0.4, where four destination rows at a time reload 64 for the same 16), each thread samples
+// four destination rows of its column.  Same integers as cubic_sample.
+#define RGT_ROWS 4                       /* destination rows per thread: a block covers 4 * RGT_ROWS of them */
+__global__ __launch_bounds__(256) void k_resize_gray_pair_tall(const unsigned char *__restrict__ a, long long sa,
+                                                               const unsigned char *__restrict__ b, long long sb, int sh, int sw,
+                                                               const CubicTab *__restrict__ xt, const CubicTab *__restrict__ yt,
+                                                               int dh, int dw, int shift, unsigned char *__restrict__ ga,
+                                                               unsigned char *__restrict__ gb, long long pitch, int lds_pitch,
+                                                               int max_rows, double *__restrict__ part)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char win[];      // [image 2][row max_rows][lds_pitch]
+    __shared__ double ws[4];
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
+    const int bx0 = blockIdx.x * 64, by0 = blockIdx.y * (4 * RGT_ROWS);
+    const int xl = bx0, xr = min(bx0 + 63, dw - 1);
+    const int c_lo = max(xt[xl].ofs - 1, 0), c_hi = min(xt[xr].ofs + 2, sw - 1);
+    const int byte0 = (c_lo * 3) & ~15, nbytes = (c_hi + 1) * 3 - byte0;
+    const int nchunk = (nbytes + 15) >> 4, rowbytes = sw * 3;
+    const int r_lo = max(yt[by0].ofs - 1, 0), r_hi = min(yt[min(by0 + 4 * RGT_ROWS - 1, dh - 1)].ofs + 2, sh - 1);
+    const int n_rows = min(r_hi - r_lo + 1, max_rows);                      // host sizes max_rows: never clipped
+    for (int e = tid; e < 2 * n_rows * nchunk; e += 256) {
+        const int rr = e / nchunk, ck = e - rr * nchunk;                    // rr = image * n_rows + row
+        const int img = rr >= n_rows ? 1 : 0, row = rr - img * n_rows;
+        const unsigned char *src = (img ? b + (size_t)(r_lo + row) * sb : a + (size_t)(r_lo + row) * sa);
+        const int off = byte0 + 16 * ck;
+        u4_t v;
+        if (off + 16 <= rowbytes) {
+            v = *(const __attribute__((address_space(1))) u4_a1_t *)(src + off);
+        } else {
+            unsigned w4[4] = {0u, 0u, 0u, 0u};
+            for (int i = 0; i < 16 && off + i < rowbytes; ++i) w4[i >> 2] |= (unsigned)src[off + i] << (8 * (i & 3));
+            v.x = w4[0]; v.y = w4[1]; v.z = w4[2]; v.w = w4[3];
+        }
+        *(u4_t *)(win + ((size_t)img * max_rows + row) * lds_pitch + 16 * ck) = v;
+    }
+    __syncthreads();
+    const int x = bx0 + tx;
+    unsigned sse = 0;
+    if (x < dw) {
+        const CubicTab X = xt[x];
+        const bool inner = X.ofs - 1 >= 0 && X.ofs + 2 <= sw - 1;
+#pragma unroll 1
+        for (int j = 0; j < RGT_ROWS; ++j) {
+            const int y = by0 + ty * RGT_ROWS + j;
+            if (y >= dh) break;
+            const CubicTab Y = yt[y];
+            int va[3], vb[3];
+#pragma unroll
+            for (int img = 0; img < 2; ++img) {
+                int acc[3] = {0, 0, 0};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int srow = min(max(Y.ofs - 1 + t, 0), sh - 1) - r_lo;
+                    const unsigned char *row = win + ((size_t)img * max_rows + srow) * lds_pitch;
+                    int v[4][3];
+                    if (inner) {
+                        unsigned wd[3];
+                        lds_tap12(row, (X.ofs - 1) * 3 - byte0, wd);
+#pragma unroll
+                        for (int q = 0; q < 12; ++q) v[q / 3][q % 3] = (int)((wd[q >> 2] >> (8 * (q & 3))) & 0xFFu);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int sx = min(max(X.ofs + k - 1, 0), sw - 1) * 3 - byte0;
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) v[k][c] = (int)row[sx + c];
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const int hs = v[0][c] * X.c[0] + v[1][c] * X.c[1] + v[2][c] * X.c[2] + v[3][c] * X.c[3];
+                        acc[c] += hs * (int)Y.c[t];
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int r = (acc[c] + (1 << 21)) >> 22;
+                    (img ? vb : va)[c] = r < 0 ? 0 : (r > 255 ? 255 : r);
+                }
+            }
+            ga[(size_t)y * pitch + x] = (unsigned char)gray_rgb(va[0], va[1], va[2], shift);
+            gb[(size_t)y * pitch + x] = (unsigned char)gray_rgb(vb[0], vb[1], vb[2], shift);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sse += (unsigned)((va[c] - vb[c]) * (va[c] - vb[c]));
+        }
+    }
+    const double sred = wave_sum_f64((double)sse);
+    if ((tid & 63) == 0) ws[tid >> 6] = sred;
+    __syncthreads();
+    if (tid == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
 __global__ void k_store_sse(const double *__restrict__ src, sr_assess_sums *__restrict__ out)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) out->sse = src[0];
@@ -4733,7 +4827,19 @@ int sr_assess_resized_u8_async(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a
         const int lp = (span + 15) / 16 * 16 + 16;                                 // + one chunk: lds_tap12 reads 16 aligned bytes
         if (32 * lp <= 64 * 1024) lds_pitch = lp;
     }
-    const dim3 block(64, 4), grid(lds_pitch ? (unsigned)((dst_w + 63) / 64) : (unsigned)((dst_w + 255) / 256), (unsigned)((dst_h + 3) / 4));
+    // gentle down-sampling: blocks of 16 destination rows that stage each source row once (k_resize_gray_pair_tall), when
+    // that is at least a quarter fewer rows than the 4 rows x 4 taps layout loads and the window fits 64 KB
+    int tall_rows = 0;
+    if (lds_pitch) {
+        int mr = 0;
+        for (int y0b = 0; y0b < dst_h; y0b += 4 * RGT_ROWS) {
+            const int lo = std::max(yt[(size_t)y0b].ofs - 1, 0), hi = std::min(yt[(size_t)std::min(y0b + 4 * RGT_ROWS - 1, dst_h - 1)].ofs + 2, h - 1);
+            mr = std::max(mr, hi - lo + 1);
+        }
+        if (mr * 4 <= 16 * RGT_ROWS * 3 && (size_t)2 * mr * lds_pitch <= 64 * 1024) tall_rows = mr;
+    }
+    const dim3 block(64, 4), grid(lds_pitch ? (unsigned)((dst_w + 63) / 64) : (unsigned)((dst_w + 255) / 256),
+                                 tall_rows ? (unsigned)((dst_h + 4 * RGT_ROWS - 1) / (4 * RGT_ROWS)) : (unsigned)((dst_h + 3) / 4));
     const size_t nblk = (size_t)grid.x * grid.y, plane = (size_t)pitch * dst_h;
     const size_t off_part = (2 * plane + 255) / 256 * 256, need = off_part + (nblk + 2 * (nblk / 1024 + 2)) * sizeof(double);
     if (need > ctx->gray_planes_bytes) {
@@ -4752,7 +4858,20 @@ int sr_assess_resized_u8_async(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a
     const double *sse_ptr = nullptr;
     {
         ProfScope ps(ctx, "resize_gray");
-        if (lds_pitch) {
+        if (tall_rows) {
+            {
+                static std::mutex mu2;
+                static std::set<int> done2;
+                std::lock_guard<std::mutex> lk(mu2);
+                if (!done2.count(ctx->device)) {
+                    HIPCHK(hipFuncSetAttribute((const void *)k_resize_gray_pair_tall, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+                    done2.insert(ctx->device);
+                }
+            }
+            hipLaunchKernelGGL(k_resize_gray_pair_tall, grid, block, (size_t)2 * tall_rows * lds_pitch, ctx->stream, d_a, (long long)stride_a,
+                               d_b, (long long)stride_b, h, w, d_xt, d_yt, dst_h, dst_w, gray_shift, ga, gb, (long long)pitch, lds_pitch,
+                               tall_rows, part);
+        } else if (lds_pitch) {
             {   // once per device (the attribute belongs to the function ON a device), under a lock: contexts of several
                 // devices / threads reach this concurrently
                 static std::mutex mu;
