@@ -968,6 +968,36 @@ __device__ __forceinline__ void gather_tile_generic(const FinalDesc &D, const fl
             if (valid & (1u << (j * 4 + k))) wacc[j][k] += w0[j][k];
 }
 
+// up_block_interior<false, YO> in packed fp32: the thread's 4 x 2 patch from rows r0 .. r0 + 2,
+// columns c0 .. c0 + 3 of a planar level.  Pairs run over the columns of equal phase, (k0, k2) and (k1, k3): with
+// A = the four taps and B = the two taps one column to the right (c0 is odd, so B is an aligned 8-byte load and A's halves
+// are aligned register pairs) the horizontal pass is  (h0, h2) = (A01 + B01 * 6) + A23,  (h1, h3) = B01 + A23  -- the
+// same operands in the same order as the scalar form, two results per instruction.  24 packed instead of 48 scalar.
+template <bool YO>
+__device__ __forceinline__ void up_block_interior_pk(const float *__restrict__ plane, int ps, int r0, int c0, float (&u)[2][4])
+{
+    f2_t h02[3], h13[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float *row = plane + (size_t)(r0 + r) * ps + c0;
+        const f4_t a = ld_f4_a4(row);
+        const f2_t b01 = *(const f2_a8_t *)(row + 1);
+        f2_t a01, a23;
+        a01.x = a.x; a01.y = a.y; a23.x = a.z; a23.y = a.w;
+        h02[r] = (a01 + b01 * 6.0f) + a23;
+        h13[r] = b01 + a23;
+    }
+    // columns k0, k2 are the even pyrUp phase (1/64 even rows, 1/16 odd rows), k1, k3 the odd one (1/16, 1/4)
+    // (YO: the patch starts on an odd row, whose two taps are rows 0 and 1; the even row follows)
+    const f2_t ev02 = ((h02[0] + h02[1] * 6.0f) + h02[2]) * (1.0f / 64.0f);
+    const f2_t ev13 = ((h13[0] + h13[1] * 6.0f) + h13[2]) * (1.0f / 16.0f);
+    const f2_t od02 = (YO ? (h02[0] + h02[1]) : (h02[1] + h02[2])) * (1.0f / 16.0f);
+    const f2_t od13 = (YO ? (h13[0] + h13[1]) : (h13[1] + h13[2])) * (1.0f / 4.0f);
+    constexpr int E = YO ? 1 : 0, O = YO ? 0 : 1;
+    u[E][0] = ev02.x; u[E][2] = ev02.y; u[E][1] = ev13.x; u[E][3] = ev13.y;
+    u[O][0] = od02.x; u[O][2] = od02.y; u[O][1] = od13.x; u[O][3] = od13.y;
+}
+
 // R_i for one level of every tile, register-blocked: one thread = 4 x 2 pixels of level i, all planes.
 // Tile-local x0 is a multiple of 4 (so the pyrUp column phase is fixed: XO = false); the row phase follows
 // the parity of the row-window start and is uniform per tile.  Same expressions as k_up_level.
@@ -995,8 +1025,8 @@ __device__ __forceinline__ void up_level_thread(const TileDev &T, int lvl, float
         const float *gs = arena + T.g_off[lvl + 1] + c * splane;
         const float *rs = arena + T.r_off[lvl + 1] + c * splane;
         if (interior) {
-            up_block_interior<false, YO>(gs, ps, r0, c0, ug);
-            up_block_interior<false, YO>(rs, ps, r0, c0, ur);
+            up_block_interior_pk<YO>(gs, ps, r0, c0, ug);
+            up_block_interior_pk<YO>(rs, ps, r0, c0, ur);
         } else {
             up_block<false, YO>(gs, hs, ws, ps, r0, c0, ug);
             up_block<false, YO>(rs, hs, ws, ps, r0, c0, ur);
@@ -1292,31 +1322,6 @@ __device__ __forceinline__ bool fused_window(const FinalDesc &D, int lxa, int ly
     return true;
 }
 
-// up_block_interior<false, false> in packed fp32: the thread's 4 x 2 patch (even row phase first) from rows r0 .. r0 + 2,
-// columns c0 .. c0 + 3 of a planar level.  Pairs run over the columns of equal phase, (k0, k2) and (k1, k3): with
-// A = the four taps and B = the two taps one column to the right (c0 is odd, so B is an aligned 8-byte load and A's halves
-// are aligned register pairs) the horizontal pass is  (h0, h2) = (A01 + B01 * 6) + A23,  (h1, h3) = B01 + A23  -- the
-// same operands in the same order as the scalar form, two results per instruction.  24 packed instead of 48 scalar.
-__device__ __forceinline__ void up_block_interior_pk(const float *__restrict__ plane, int ps, int r0, int c0, float (&u)[2][4])
-{
-    f2_t h02[3], h13[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const float *row = plane + (size_t)(r0 + r) * ps + c0;
-        const f4_t a = ld_f4_a4(row);
-        const f2_t b01 = *(const f2_a8_t *)(row + 1);
-        f2_t a01, a23;
-        a01.x = a.x; a01.y = a.y; a23.x = a.z; a23.y = a.w;
-        h02[r] = (a01 + b01 * 6.0f) + a23;
-        h13[r] = b01 + a23;
-    }
-    // columns k0, k2 are the even pyrUp phase (1/64 even rows, 1/16 odd rows), k1, k3 the odd one (1/16, 1/4)
-    const f2_t ev02 = ((h02[0] + h02[1] * 6.0f) + h02[2]) * (1.0f / 64.0f), od02 = (h02[1] + h02[2]) * (1.0f / 16.0f);
-    const f2_t ev13 = ((h13[0] + h13[1] * 6.0f) + h13[2]) * (1.0f / 16.0f), od13 = (h13[1] + h13[2]) * (1.0f / 4.0f);
-    u[0][0] = ev02.x; u[0][2] = ev02.y; u[0][1] = ev13.x; u[0][3] = ev13.y;
-    u[1][0] = od02.x; u[1][2] = od02.y; u[1][1] = od13.x; u[1][3] = od13.y;
-}
-
 // Stage 1: R_1 and G_1 of the window into LDS, interleaved per pixel as (g, r) pairs: lds[plane][row][col][2] -- stage 2
 // then reads a pixel's two values as one aligned 8-byte pair and runs the pyrUp of both arrays in packed fp32 (v_pk_*,
 // IEEE per element: same roundings as the scalar form).  One item = one 4 x 2 patch of one plane = up_level_thread's work.
@@ -1351,8 +1356,8 @@ __device__ __forceinline__ void fused_stage1(const FinalDesc &D, const float *__
             const float *gs = arena + D.g2 + c * plane2, *rs = arena + D.r2 + c * plane2;
             float ug[2][4], ur[2][4];
             if (interior) {
-                up_block_interior_pk(gs, D.P2, r0, c0, ug);
-                up_block_interior_pk(rs, D.P2, r0, c0, ur);
+                up_block_interior_pk<false>(gs, D.P2, r0, c0, ug);
+                up_block_interior_pk<false>(rs, D.P2, r0, c0, ur);
             } else {
                 up_block<false, false>(gs, D.H2, D.W2, D.P2, r0, c0, ug);
                 up_block<false, false>(rs, D.H2, D.W2, D.P2, r0, c0, ur);
