@@ -11,12 +11,20 @@
 //                         owns 64 x 16 output pixels of one channel at a time.
 // Everything is HBM-bound byte / fp32 work (3 B in, 24 B of a / b out and back in, 3 B out per pixel); no MFMA.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 #include "sr_ctx.h"
 
 namespace {
+
+// experiments / A-B runs: NAME=0 switches a default-on path off
+bool env_flag_off(const char *name)
+{
+    const char *e = std::getenv(name);
+    return e && e[0] == '0';
+}
 
 __device__ __forceinline__ int cc_reflect101(int p, int n)
 {
@@ -394,6 +402,207 @@ __global__ __launch_bounds__(256) void k_cc_apply8(const unsigned char *__restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 3: the guided filter in ONE kernel -- a and b never leave the CU (the two-pass form above writes and re-reads 24
+// bytes per pixel and spends most of its time waiting for those loads).  Used when the guide table is integer-valued
+// (histogram matching and method 'none': every entry of the table is a whole number 0..255), because then the four
+// first-stage box sums are sums of integers < 2^24 -- exact in any order, so they run as 32-bit sliding sums (the sums of
+// g and s share one word, 16 bits each) and mean = (float)S * (1 / 64) is the float the oracle's fp64 sum rounds to.
+// The second stage (box means of a and b, arbitrary floats) keeps the oracle's fp64 order: row sums left to right, then
+// top to bottom.
+//
+// A block of 512 threads owns 64 x 32 output pixels and takes the channels in turn:
+//   load   the (64 + 14) x (32 + 14) input window, all channels, once (dword loads; border blocks reflect per byte);
+//   B      column sums of 8 rows of (g | s << 16), g * s, g * g: item = (column, 7-row segment), sliding;
+//   C      row sums of 8 columns of those, sliding, then a = cov / (var + eps), b = mean_s - a * mean_g at the
+//          (64 + 7) x (32 + 7) positions the second stage reads; positions outside the image take the value of their
+//          BORDER_REFLECT_101 mirror position (cv2.blur's border rule applied to the a / b images: a plain copy);
+//   D, E   the ordered fp64 row / column sums of a and b (four neighbouring sums from eleven values, as above), then
+//          u8(clip(mean_a * g + mean_b)) written over the input byte it came from;
+//   store  the window's interior, now the output tile, with dword stores.
+// LDS: 39 KB (column sums, later the fp64 row sums) + 22 KB (a, b) + 1 KB table + 11 KB window = 73 KB, two blocks per CU.
+// ---------------------------------------------------------------------------------------------------------------
+#define FG_TH 32
+#define FG_TW 64
+#define FG_NT 512
+#define FG_AH (FG_TH + 7)                  /* rows of a / b */
+#define FG_AW (FG_TW + 7)                  /* columns of a / b */
+#define FG_AP 72                           /* their pitch */
+#define FG_IH (FG_TH + 14)                 /* input window */
+#define FG_IW (FG_TW + 14)
+#define FG_VP 80                           /* pitch of the column-sum planes */
+#define FG_SEG 7                           /* rows per item of pass B: 6 segments cover the 39 rows */
+#define FG_Y_BYTES (FG_AH * FG_TW * 16)    /* fp64 row sums of (a, b): 39936 >= 3 * 39 * 80 * 4 */
+#define FG_X_BYTES (2 * FG_AH * FG_AP * 4)
+static_assert(FG_Y_BYTES >= 3 * FG_AH * FG_VP * 4, "column-sum planes must fit the row-sum region");
+
+typedef unsigned fg_u32_a1_t __attribute__((aligned(1)));
+
+__global__ __launch_bounds__(FG_NT) void k_cc_fused8(const unsigned char *__restrict__ img, long long stride, int h, int w, int cn,
+                                                     const unsigned char *__restrict__ glutb, float eps,
+                                                     unsigned char *__restrict__ out, long long ostride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned *V1 = (unsigned *)smem, *V2 = V1 + FG_AH * FG_VP, *V3 = V2 + FG_AH * FG_VP;
+    double *hs = (double *)smem;                                  // [AH][64 positions][2] once V1..V3 are consumed
+    float *a_p = (float *)(smem + FG_Y_BYTES), *b_p = a_p + FG_AH * FG_AP;
+    unsigned char *lutb = smem + FG_Y_BYTES + FG_X_BYTES;         // [cn][256]
+    unsigned char *raw = lutb + 1024;                             // [IH][rawp], pixels interleaved as in the image
+    const int rowb = cn * FG_IW, rawp = (rowb + 3) & ~3;
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * FG_TW, y0 = blockIdx.y * FG_TH;
+
+    for (int i = tid; i < cn * 256; i += FG_NT) lutb[i] = glutb[i];
+    if (x0 >= 8 && x0 - 8 + FG_IW <= w && y0 >= 8 && y0 - 8 + FG_IH <= h) {
+        const int ndw = rowb >> 2, tail = rowb & 3, per = ndw + (tail ? 1 : 0);
+        for (int e = tid; e < FG_IH * per; e += FG_NT) {
+            const int i = e / per, d = e - i * per;
+            const unsigned char *src = img + (size_t)(y0 - 8 + i) * stride + (size_t)(x0 - 8) * cn + 4 * d;
+            if (d < ndw) *(unsigned *)(raw + i * rawp + 4 * d) = *(const __attribute__((address_space(1))) fg_u32_a1_t *)src;
+            else for (int t = 0; t < tail; ++t) raw[i * rawp + 4 * d + t] = src[t];
+        }
+    } else {
+        for (int e = tid; e < FG_IH * rowb; e += FG_NT) {
+            const int i = e / rowb, r = e - i * rowb, j = r / cn, c = r - j * cn;
+            raw[i * rawp + r] = img[(size_t)cc_reflect101(y0 - 8 + i, h) * stride + (size_t)cc_reflect101(x0 - 8 + j, w) * cn + c];
+        }
+    }
+    const bool edge = y0 < 4 || y0 - 4 + FG_AH > h || x0 < 4 || x0 - 4 + FG_AW > w;   // some a / b position lies outside
+    __syncthreads();
+
+    for (int c = 0; c < cn; ++c) {
+        const unsigned char *lt = lutb + c * 256;
+        // ---- B: column sums ----
+        if (tid < 6 * FG_IW) {
+            const int seg = tid / FG_IW, col = tid - seg * FG_IW, r0 = seg * FG_SEG;
+            const unsigned char *rp = raw + col * cn + c;
+            unsigned p1[FG_SEG + 7], p2[FG_SEG + 7], p3[FG_SEG + 7];
+#pragma unroll
+            for (int k = 0; k < FG_SEG + 7; ++k) {
+                const int i = min(r0 + k, FG_IH - 1);
+                const unsigned s = rp[i * rawp], g = lt[s];
+                p1[k] = g | (s << 16);
+                // opaque products: hipcc 7.2 folds sums of byte products into v_perm_b32 + v_dot4_u32_u8 and gets them wrong
+                asm("v_mul_u32_u24_e32 %0, %1, %2" : "=v"(p2[k]) : "v"(g), "v"(s));
+                asm("v_mul_u32_u24_e32 %0, %1, %1" : "=v"(p3[k]) : "v"(g));
+            }
+            unsigned s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s1 += p1[k]; s2 += p2[k]; s3 += p3[k]; }
+#pragma unroll
+            for (int k = 0; k < FG_SEG; ++k) {
+                if (k > 0) {
+                    s1 += p1[k + 7] - p1[k - 1];
+                    s2 += p2[k + 7] - p2[k - 1];
+                    s3 += p3[k + 7] - p3[k - 1];
+                }
+                if (r0 + k < FG_AH) {
+                    V1[(r0 + k) * FG_VP + col] = s1;
+                    V2[(r0 + k) * FG_VP + col] = s2;
+                    V3[(r0 + k) * FG_VP + col] = s3;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- C: row sums, a and b ----
+        if (tid < FG_AH * 12) {
+            const int row = tid / 12, q0 = (tid - row * 12) * 6;
+            const unsigned *v1 = V1 + row * FG_VP + q0, *v2 = V2 + row * FG_VP + q0, *v3 = V3 + row * FG_VP + q0;
+            unsigned p1[13], p2[13], p3[13];
+#pragma unroll
+            for (int k = 0; k < 13; ++k) { p1[k] = v1[k]; p2[k] = v2[k]; p3[k] = v3[k]; }
+            unsigned s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s1 += p1[k]; s2 += p2[k]; s3 += p3[k]; }
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                if (t > 0) {
+                    s1 += p1[t + 7] - p1[t - 1];
+                    s2 += p2[t + 7] - p2[t - 1];
+                    s3 += p3[t + 7] - p3[t - 1];
+                }
+                const float mg = (float)(s1 & 0xFFFFu) * 0.015625f, ms = (float)(s1 >> 16) * 0.015625f;
+                const float mgs = (float)s2 * 0.015625f, mgg = (float)s3 * 0.015625f;
+                const float cov = mgs - mg * ms, var = mgg - mg * mg;
+                const float a = cov / (var + eps);
+                const float b = ms - a * mg;
+                if (q0 + t < FG_AW) {
+                    a_p[row * FG_AP + q0 + t] = a;
+                    b_p[row * FG_AP + q0 + t] = b;
+                }
+            }
+        }
+        __syncthreads();
+        if (edge) {                                               // block-uniform
+            for (int e = tid; e < FG_AH * FG_AW; e += FG_NT) {
+                const int r = e / FG_AW, q = e - r * FG_AW;
+                const int py = y0 - 4 + r, px = x0 - 4 + q;
+                if (py < 0 || py >= h || px < 0 || px >= w) {
+                    const int sr = cc_reflect101(py, h) - (y0 - 4), sq = cc_reflect101(px, w) - (x0 - 4);
+                    if (sr >= 0 && sr < FG_AH && sq >= 0 && sq < FG_AW) {   // else: a position no stored pixel reads
+                        a_p[r * FG_AP + q] = a_p[sr * FG_AP + sq];
+                        b_p[r * FG_AP + q] = b_p[sr * FG_AP + sq];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // ---- D: ordered row sums of a and b; the sums of output column 4 gx + j go to position j * 16 + gx of their row ----
+        for (int e = tid; e < FG_AH * 16; e += FG_NT) {
+            const int py = e >> 4, gx = e & 15;
+            const float4 *ar = (const float4 *)(a_p + py * FG_AP + 4 * gx), *br = (const float4 *)(b_p + py * FG_AP + 4 * gx);
+            const float4 a0 = ar[0], a1 = ar[1], a2 = ar[2], b0 = br[0], b1 = br[1], b2 = br[2];
+            const double v0[11] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z};
+            const double v1[11] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z};
+            double o0[4], o1[4];
+            cc8_sums(v0, o0);
+            cc8_sums(v1, o1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *(double2 *)(hs + ((size_t)py * FG_TW + j * 16 + gx) * 2) = make_double2(o0[j], o1[j]);
+        }
+        __syncthreads();
+        // ---- E: ordered column sums, output ----
+        {
+            const int gy = tid >> 6, l = tid & 63, ox = 4 * (l & 15) + (l >> 4);
+            double v0[11], v1[11];
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                const double2 t = *(const double2 *)(hs + ((size_t)(4 * gy + k) * FG_TW + l) * 2);
+                v0[k] = t.x;
+                v1[k] = t.y;
+            }
+            double ta[4], tb[4];
+            cc8_sums(v0, ta);
+            cc8_sums(v1, tb);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned char *px = raw + (4 * gy + j + 8) * rawp + (ox + 8) * cn + c;
+                const float ma = (float)(ta[j] * 0.015625), mb = (float)(tb[j] * 0.015625);
+                const float g = (float)lt[*px];
+                const float r = ma * g + mb;
+                const float cl = r < 0.0f ? 0.0f : (r > 255.0f ? 255.0f : r);
+                *px = (unsigned char)cl;
+            }
+        }
+        __syncthreads();                                          // hs becomes V1..V3 again
+    }
+    const int tileb = FG_TW * cn;                                 // bytes of one output row of the block
+    if (x0 + FG_TW <= w && y0 + FG_TH <= h) {
+        const int ndw = tileb >> 2;                               // 64 cn is a multiple of 4
+        for (int e = tid; e < FG_TH * ndw; e += FG_NT) {
+            const int oy = e / ndw, d = e - oy * ndw;
+            *(__attribute__((address_space(1))) fg_u32_a1_t *)(out + (size_t)(y0 + oy) * ostride + (size_t)x0 * cn + 4 * d) =
+                *(const unsigned *)(raw + (oy + 8) * rawp + 8 * cn + 4 * d);
+        }
+    } else {
+        const int vw = min(FG_TW, w - x0) * cn, vh = min(FG_TH, h - y0);
+        for (int e = tid; e < vh * tileb; e += FG_NT) {
+            const int oy = e / tileb, r = e - oy * tileb;
+            if (r < vw) out[(size_t)(y0 + oy) * ostride + (size_t)x0 * cn + r] = raw[(oy + 8) * rawp + 8 * cn + r];
+        }
+    }
+}
+
 
 // ---------------------------------------------------------------------------------------------------------------
 // The OTHER branch of BlendingModule._guided_filter (blending_module.py:1108-1111): cv2.ximgproc.guidedFilter(guide, src,
@@ -611,7 +820,7 @@ int sr_color_correct_u8(sr_ctx *ctx, const uint8_t *d_img, int64_t stride, int h
     const size_t npx = (size_t)h * w * cn;
     const size_t tab_bytes = 4 * 256 * sizeof(float);
     void *scr = nullptr;
-    int rc = ctx_scratch(ctx, tab_bytes + 256, &scr);
+    int rc = ctx_scratch(ctx, tab_bytes + 1024 + 256, &scr);
     if (rc) return rc;
     float *d_glut = (float *)scr;
     HIPCHK(upload_small(ctx, d_glut, h_glut, (size_t)cn * 256 * sizeof(float)));
@@ -674,6 +883,28 @@ int sr_color_correct_u8(sr_ctx *ctx, const uint8_t *d_img, int64_t stride, int h
         if (rc2) return rc2;
         if (es2 != hipSuccess) return sr_set_error(SR_ERR_HIP, "sr_color_correct_u8: %s", hipGetErrorString(es2));
         return SR_OK;
+    }
+    if (radius == CC8_R && h >= 16 && w >= 16 && !env_flag_off("SR_CC_FUSED")) {
+        // the reference's setting with an integer-valued guide table (histogram matching, method 'none'): one fused kernel
+        unsigned char tabb[4 * 256];
+        bool whole = true;
+        for (int i = 0; i < cn * 256 && whole; ++i) {
+            const float v = h_glut[i];
+            whole = v >= 0.0f && v <= 255.0f && v == (float)(int)v;
+            tabb[i] = (unsigned char)(whole ? (int)v : 0);
+        }
+        if (whole) {
+            unsigned char *d_glutb = (unsigned char *)scr + tab_bytes;
+            HIPCHK(upload_small(ctx, d_glutb, tabb, (size_t)cn * 256));
+            const size_t lds = (size_t)FG_Y_BYTES + FG_X_BYTES + 1024 + (size_t)FG_IH * ((cn * FG_IW + 3) & ~3);
+            (void)hipFuncSetAttribute((const void *)k_cc_fused8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            {
+                ProfScope ps(ctx, "guided_fused");
+                hipLaunchKernelGGL(k_cc_fused8, dim3((w + FG_TW - 1) / FG_TW, (h + FG_TH - 1) / FG_TH), dim3(FG_NT), lds, ctx->stream,
+                                   d_img, (long long)stride, h, w, cn, (const unsigned char *)d_glutb, eps, d_out, (long long)out_stride);
+            }
+            return check_launch("guided_fused");
+        }
     }
     // a / b planes (8 bytes per sample): an allocation of their own, released when the call is done
     float *d_a = nullptr;

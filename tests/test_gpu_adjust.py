@@ -77,6 +77,34 @@ def test_color_correction_gray_edges_and_histogram(ctx, rng):
         bm.color_correction(img, img[..., 0])
 
 
+@pytest.mark.parametrize("shape", [(16, 16, 3), (17, 64, 3), (40, 71, 1), (97, 211, 3), (33, 130, 4), (200, 300, 3), (64, 128, 3),
+                                   (46, 78, 3), (47, 79, 1)])
+def test_color_correction_fused_guided_filter(rng, shape, monkeypatch):
+    """The one-kernel guided filter (k_cc_fused8: integer guide table -> exact 32-bit sliding sums for the first stage, a / b
+    kept in LDS) against the oracle AND against the two-pass kernels it replaces (SR_CC_FUSED=0): block interiors, every
+    border, ragged right / bottom edges, images barely larger than the window, 1 / 3 / 4 channels.  'none' keeps the identity
+    table (guide == source), 'histogram' a non-trivial one."""
+    from blending_module import BlendingModule
+    bm = BlendingModule()
+    h, w, cn = shape
+    img = _scene(rng, h, w, cn)
+    ref = np.clip(_scene(rng, 50, 60, cn).astype(np.int16) // 2 + 70, 0, 255).astype(np.uint8)
+    if cn == 1:
+        img, ref = img[..., 0], ref[..., 0]
+    for method in ("histogram", "other"):
+        want = onp.color_correction(img, ref, method=method)
+        got = bm.color_correction(img, ref, method=method)
+        assert np.array_equal(got, want), (shape, method, int((got != want).sum()))
+        monkeypatch.setenv("SR_CC_FUSED", "0")
+        two_pass = bm.color_correction(img, ref, method=method)
+        monkeypatch.delenv("SR_CC_FUSED")
+        assert np.array_equal(two_pass, want), (shape, method)
+    flat = np.full_like(img, 77)                                 # zero variance everywhere: a = 0 / eps, b = mean
+    assert np.array_equal(bm.color_correction(flat, ref, method="other"), onp.color_correction(flat, ref, method="other"))
+    noise = rng.integers(0, 256, img.shape, dtype=np.uint8)      # full-range noise
+    assert np.array_equal(bm.color_correction(noise, ref), onp.color_correction(noise, ref))
+
+
 def test_mixed_channel_tiles_raise(rng):
     from blending_module import BlendingModule, TileInfo
     bm = BlendingModule()
