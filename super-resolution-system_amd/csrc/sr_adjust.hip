@@ -431,56 +431,92 @@ __global__ __launch_bounds__(256) void k_cc_apply8(const unsigned char *__restri
 #define FG_IH (FG_TH + 14)                 /* input window */
 #define FG_IW (FG_TW + 14)
 #define FG_VP 80                           /* pitch of the column-sum planes */
-#define FG_SEG 7                           /* rows per item of pass B: 6 segments cover the 39 rows */
+#ifndef FG_SEG
+#define FG_SEG 7                           /* rows per item of pass B */
+#endif
+#define FG_NSEG ((FG_AH + FG_SEG - 1) / FG_SEG)   /* 6 x 7 rows; 4 x 10 and 3 x 13 issue 8 % fewer instructions and are 2-3 % slower: latency, not issue */
 #define FG_Y_BYTES (FG_AH * FG_TW * 16)    /* fp64 row sums of (a, b): 39936 >= 3 * 39 * 80 * 4 */
 #define FG_X_BYTES (2 * FG_AH * FG_AP * 4)
 static_assert(FG_Y_BYTES >= 3 * FG_AH * FG_VP * 4, "column-sum planes must fit the row-sum region");
 
 typedef unsigned fg_u32_a1_t __attribute__((aligned(1)));
+typedef float fg_f2_t __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(FG_NT) void k_cc_fused8(const unsigned char *__restrict__ img, long long stride, int h, int w, int cn,
+// four outputs j = 0..3, each v[j] + v[j + 1] + ... + v[j + 7] in that order (cc8_sums without the leading 0.0 + v[j]: that
+// addition only turns a -0.0 into +0.0, which no stored byte can tell apart)
+__device__ __forceinline__ void fg_sums(const double (&v)[11], double (&o)[4])
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double t = v[j];
+#pragma unroll
+        for (int k = 1; k < CC8_R; ++k) t += v[j + k];
+        o[j] = t;
+    }
+}
+
+// cov / den for two positions at once, IEEE-correct: the fma chain hipcc emits for an fp32 division (rcp, one Newton step,
+// quotient, two residual corrections) without the v_div_scale / v_div_fixup wrapping, which is the identity here -- den =
+// var + eps lies in [0.006, 65026] (var >= -0.004: the rounding of mean_g * mean_g) and cov is 0 or 2^-13 <= |cov| <= 65025,
+// so nothing is scaled, nothing over- or underflows.  v_pk_mul_f32 / v_pk_fma_f32 round per element like the scalar forms.
+__device__ __forceinline__ fg_f2_t fg_div2(fg_f2_t num, fg_f2_t den)
+{
+    fg_f2_t r;
+    r.x = __builtin_amdgcn_rcpf(den.x);
+    r.y = __builtin_amdgcn_rcpf(den.y);
+    const fg_f2_t nd = -den, one = {1.0f, 1.0f};
+    r = __builtin_elementwise_fma(__builtin_elementwise_fma(nd, r, one), r, r);
+    fg_f2_t t = num * r;
+    t = __builtin_elementwise_fma(__builtin_elementwise_fma(nd, t, num), r, t);
+    return __builtin_elementwise_fma(__builtin_elementwise_fma(nd, t, num), r, t);
+}
+
+template <int CN>
+__global__ __launch_bounds__(FG_NT) void k_cc_fused8(const unsigned char *__restrict__ img, long long stride, int h, int w,
                                                      const unsigned char *__restrict__ glutb, float eps,
                                                      unsigned char *__restrict__ out, long long ostride)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int rowb = CN * FG_IW, rawp = (rowb + 3) & ~3;
+    constexpr int LUT0 = FG_Y_BYTES + FG_X_BYTES, RAW0 = LUT0 + 1024;
     unsigned *V1 = (unsigned *)smem, *V2 = V1 + FG_AH * FG_VP, *V3 = V2 + FG_AH * FG_VP;
     double *hs = (double *)smem;                                  // [AH][64 positions][2] once V1..V3 are consumed
     float *a_p = (float *)(smem + FG_Y_BYTES), *b_p = a_p + FG_AH * FG_AP;
-    unsigned char *lutb = smem + FG_Y_BYTES + FG_X_BYTES;         // [cn][256]
-    unsigned char *raw = lutb + 1024;                             // [IH][rawp], pixels interleaved as in the image
-    const int rowb = cn * FG_IW, rawp = (rowb + 3) & ~3;
+    unsigned char *lutb = smem + LUT0;                            // [CN][256]
+    unsigned char *raw = smem + RAW0;                             // [IH][rawp], pixels interleaved as in the image
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * FG_TW, y0 = blockIdx.y * FG_TH;
 
-    for (int i = tid; i < cn * 256; i += FG_NT) lutb[i] = glutb[i];
+    for (int i = tid; i < CN * 256; i += FG_NT) lutb[i] = glutb[i];
     if (x0 >= 8 && x0 - 8 + FG_IW <= w && y0 >= 8 && y0 - 8 + FG_IH <= h) {
-        const int ndw = rowb >> 2, tail = rowb & 3, per = ndw + (tail ? 1 : 0);
+        constexpr int ndw = rowb >> 2, tail = rowb & 3, per = ndw + (tail ? 1 : 0);
         for (int e = tid; e < FG_IH * per; e += FG_NT) {
             const int i = e / per, d = e - i * per;
-            const unsigned char *src = img + (size_t)(y0 - 8 + i) * stride + (size_t)(x0 - 8) * cn + 4 * d;
+            const unsigned char *src = img + (size_t)(y0 - 8 + i) * stride + (size_t)(x0 - 8) * CN + 4 * d;
             if (d < ndw) *(unsigned *)(raw + i * rawp + 4 * d) = *(const __attribute__((address_space(1))) fg_u32_a1_t *)src;
             else for (int t = 0; t < tail; ++t) raw[i * rawp + 4 * d + t] = src[t];
         }
     } else {
         for (int e = tid; e < FG_IH * rowb; e += FG_NT) {
-            const int i = e / rowb, r = e - i * rowb, j = r / cn, c = r - j * cn;
-            raw[i * rawp + r] = img[(size_t)cc_reflect101(y0 - 8 + i, h) * stride + (size_t)cc_reflect101(x0 - 8 + j, w) * cn + c];
+            const int i = e / rowb, r = e - i * rowb, j = r / CN, c = r - j * CN;
+            raw[i * rawp + r] = img[(size_t)cc_reflect101(y0 - 8 + i, h) * stride + (size_t)cc_reflect101(x0 - 8 + j, w) * CN + c];
         }
     }
     const bool edge = y0 < 4 || y0 - 4 + FG_AH > h || x0 < 4 || x0 - 4 + FG_AW > w;   // some a / b position lies outside
     __syncthreads();
 
-    for (int c = 0; c < cn; ++c) {
+#pragma unroll
+    for (int c = 0; c < CN; ++c) {                                // unrolled: table and window offsets become immediates
         const unsigned char *lt = lutb + c * 256;
         // ---- B: column sums ----
-        if (tid < 6 * FG_IW) {
-            const int seg = tid / FG_IW, col = tid - seg * FG_IW, r0 = seg * FG_SEG;
-            const unsigned char *rp = raw + col * cn + c;
+        if (tid < FG_NSEG * FG_IW) {
+            // the last segment ends with row 38 and repeats rows of the one before (same values): no row guards
+            const int seg = tid / FG_IW, col = tid - seg * FG_IW, r0 = min(seg * FG_SEG, FG_AH - FG_SEG);
+            const unsigned char *rp = raw + r0 * rawp + col * CN + c;
             unsigned p1[FG_SEG + 7], p2[FG_SEG + 7], p3[FG_SEG + 7];
 #pragma unroll
             for (int k = 0; k < FG_SEG + 7; ++k) {
-                const int i = min(r0 + k, FG_IH - 1);
-                const unsigned s = rp[i * rawp], g = lt[s];
+                const unsigned s = rp[k * rawp], g = lt[s];
                 p1[k] = g | (s << 16);
                 // opaque products: hipcc 7.2 folds sums of byte products into v_perm_b32 + v_dot4_u32_u8 and gets them wrong
                 asm("v_mul_u32_u24_e32 %0, %1, %2" : "=v"(p2[k]) : "v"(g), "v"(s));
@@ -496,39 +532,48 @@ __global__ __launch_bounds__(FG_NT) void k_cc_fused8(const unsigned char *__rest
                     s2 += p2[k + 7] - p2[k - 1];
                     s3 += p3[k + 7] - p3[k - 1];
                 }
-                if (r0 + k < FG_AH) {
-                    V1[(r0 + k) * FG_VP + col] = s1;
-                    V2[(r0 + k) * FG_VP + col] = s2;
-                    V3[(r0 + k) * FG_VP + col] = s3;
-                }
+                V1[(r0 + k) * FG_VP + col] = s1;
+                V2[(r0 + k) * FG_VP + col] = s2;
+                V3[(r0 + k) * FG_VP + col] = s3;
             }
         }
         __syncthreads();
-        // ---- C: row sums, a and b ----
+        // ---- C: row sums, a and b (two positions per packed instruction) ----
         if (tid < FG_AH * 12) {
             const int row = tid / 12, q0 = (tid - row * 12) * 6;
             const unsigned *v1 = V1 + row * FG_VP + q0, *v2 = V2 + row * FG_VP + q0, *v3 = V3 + row * FG_VP + q0;
             unsigned p1[13], p2[13], p3[13];
 #pragma unroll
             for (int k = 0; k < 13; ++k) { p1[k] = v1[k]; p2[k] = v2[k]; p3[k] = v3[k]; }
-            unsigned s1 = 0, s2 = 0, s3 = 0;
+            unsigned s1[6], s2[6], s3[6];
+            s1[0] = s2[0] = s3[0] = 0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { s1 += p1[k]; s2 += p2[k]; s3 += p3[k]; }
+            for (int k = 0; k < 8; ++k) { s1[0] += p1[k]; s2[0] += p2[k]; s3[0] += p3[k]; }
 #pragma unroll
-            for (int t = 0; t < 6; ++t) {
-                if (t > 0) {
-                    s1 += p1[t + 7] - p1[t - 1];
-                    s2 += p2[t + 7] - p2[t - 1];
-                    s3 += p3[t + 7] - p3[t - 1];
-                }
-                const float mg = (float)(s1 & 0xFFFFu) * 0.015625f, ms = (float)(s1 >> 16) * 0.015625f;
-                const float mgs = (float)s2 * 0.015625f, mgg = (float)s3 * 0.015625f;
-                const float cov = mgs - mg * ms, var = mgg - mg * mg;
-                const float a = cov / (var + eps);
-                const float b = ms - a * mg;
-                if (q0 + t < FG_AW) {
-                    a_p[row * FG_AP + q0 + t] = a;
-                    b_p[row * FG_AP + q0 + t] = b;
+            for (int t = 1; t < 6; ++t) {
+                s1[t] = s1[t - 1] + (p1[t + 7] - p1[t - 1]);
+                s2[t] = s2[t - 1] + (p2[t + 7] - p2[t - 1]);
+                s3[t] = s3[t - 1] + (p3[t + 7] - p3[t - 1]);
+            }
+            const fg_f2_t k64 = {0.015625f, 0.015625f}, e2 = {eps, eps};
+#pragma unroll
+            for (int t = 0; t < 6; t += 2) {
+                fg_f2_t mg, ms, mgs, mgg;
+                mg.x = (float)(s1[t] & 0xFFFFu);      mg.y = (float)(s1[t + 1] & 0xFFFFu);
+                ms.x = (float)(s1[t] >> 16);          ms.y = (float)(s1[t + 1] >> 16);
+                mgs.x = (float)s2[t];                 mgs.y = (float)s2[t + 1];
+                mgg.x = (float)s3[t];                 mgg.y = (float)s3[t + 1];
+                mg = mg * k64; ms = ms * k64; mgs = mgs * k64; mgg = mgg * k64;
+                const fg_f2_t cov = mgs - mg * ms, var = mgg - mg * mg;
+                const fg_f2_t a = fg_div2(cov, var + e2);
+                const fg_f2_t b = ms - a * mg;
+                if (q0 + t < FG_AW) {                              // q0 + t is even, FG_AW odd: the pair's second half may be beyond
+                    a_p[row * FG_AP + q0 + t] = a.x;
+                    b_p[row * FG_AP + q0 + t] = b.x;
+                    if (q0 + t + 1 < FG_AW) {
+                        a_p[row * FG_AP + q0 + t + 1] = a.y;
+                        b_p[row * FG_AP + q0 + t + 1] = b.y;
+                    }
                 }
             }
         }
@@ -555,8 +600,8 @@ __global__ __launch_bounds__(FG_NT) void k_cc_fused8(const unsigned char *__rest
             const double v0[11] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z};
             const double v1[11] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z};
             double o0[4], o1[4];
-            cc8_sums(v0, o0);
-            cc8_sums(v1, o1);
+            fg_sums(v0, o0);
+            fg_sums(v1, o1);
 #pragma unroll
             for (int j = 0; j < 4; ++j) *(double2 *)(hs + ((size_t)py * FG_TW + j * 16 + gx) * 2) = make_double2(o0[j], o1[j]);
         }
@@ -572,33 +617,32 @@ __global__ __launch_bounds__(FG_NT) void k_cc_fused8(const unsigned char *__rest
                 v1[k] = t.y;
             }
             double ta[4], tb[4];
-            cc8_sums(v0, ta);
-            cc8_sums(v1, tb);
+            fg_sums(v0, ta);
+            fg_sums(v1, tb);
+            unsigned char *px = raw + (4 * gy + 8) * rawp + (ox + 8) * CN + c;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                unsigned char *px = raw + (4 * gy + j + 8) * rawp + (ox + 8) * cn + c;
                 const float ma = (float)(ta[j] * 0.015625), mb = (float)(tb[j] * 0.015625);
-                const float g = (float)lt[*px];
-                const float r = ma * g + mb;
-                const float cl = r < 0.0f ? 0.0f : (r > 255.0f ? 255.0f : r);
-                *px = (unsigned char)cl;
+                const float g = (float)lt[px[j * rawp]];
+                const float r = ma * g + mb;                       // finite: clip = median of (r, 0, 255)
+                px[j * rawp] = (unsigned char)__builtin_amdgcn_fmed3f(r, 0.0f, 255.0f);
             }
         }
         __syncthreads();                                          // hs becomes V1..V3 again
     }
-    const int tileb = FG_TW * cn;                                 // bytes of one output row of the block
+    constexpr int tileb = FG_TW * CN;                             // bytes of one output row of the block
     if (x0 + FG_TW <= w && y0 + FG_TH <= h) {
-        const int ndw = tileb >> 2;                               // 64 cn is a multiple of 4
+        constexpr int ndw = tileb >> 2;                           // 64 CN is a multiple of 4
         for (int e = tid; e < FG_TH * ndw; e += FG_NT) {
             const int oy = e / ndw, d = e - oy * ndw;
-            *(__attribute__((address_space(1))) fg_u32_a1_t *)(out + (size_t)(y0 + oy) * ostride + (size_t)x0 * cn + 4 * d) =
-                *(const unsigned *)(raw + (oy + 8) * rawp + 8 * cn + 4 * d);
+            *(__attribute__((address_space(1))) fg_u32_a1_t *)(out + (size_t)(y0 + oy) * ostride + (size_t)x0 * CN + 4 * d) =
+                *(const unsigned *)(raw + (oy + 8) * rawp + 8 * CN + 4 * d);
         }
     } else {
-        const int vw = min(FG_TW, w - x0) * cn, vh = min(FG_TH, h - y0);
+        const int vw = min(FG_TW, w - x0) * CN, vh = min(FG_TH, h - y0);
         for (int e = tid; e < vh * tileb; e += FG_NT) {
             const int oy = e / tileb, r = e - oy * tileb;
-            if (r < vw) out[(size_t)(y0 + oy) * ostride + (size_t)x0 * cn + r] = raw[(oy + 8) * rawp + 8 * cn + r];
+            if (r < vw) out[(size_t)(y0 + oy) * ostride + (size_t)x0 * CN + r] = raw[(oy + 8) * rawp + 8 * CN + r];
         }
     }
 }
@@ -897,11 +941,22 @@ int sr_color_correct_u8(sr_ctx *ctx, const uint8_t *d_img, int64_t stride, int h
             unsigned char *d_glutb = (unsigned char *)scr + tab_bytes;
             HIPCHK(upload_small(ctx, d_glutb, tabb, (size_t)cn * 256));
             const size_t lds = (size_t)FG_Y_BYTES + FG_X_BYTES + 1024 + (size_t)FG_IH * ((cn * FG_IW + 3) & ~3);
-            (void)hipFuncSetAttribute((const void *)k_cc_fused8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            const void *kf = cn == 1 ? (const void *)k_cc_fused8<1> : cn == 2 ? (const void *)k_cc_fused8<2>
+                             : cn == 3 ? (const void *)k_cc_fused8<3> : (const void *)k_cc_fused8<4>;
+            (void)hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             {
                 ProfScope ps(ctx, "guided_fused");
-                hipLaunchKernelGGL(k_cc_fused8, dim3((w + FG_TW - 1) / FG_TW, (h + FG_TH - 1) / FG_TH), dim3(FG_NT), lds, ctx->stream,
-                                   d_img, (long long)stride, h, w, cn, (const unsigned char *)d_glutb, eps, d_out, (long long)out_stride);
+                const dim3 grid((w + FG_TW - 1) / FG_TW, (h + FG_TH - 1) / FG_TH);
+                const unsigned char *lb = d_glutb;
+#define FG_LAUNCH(N) hipLaunchKernelGGL(k_cc_fused8<N>, grid, dim3(FG_NT), lds, ctx->stream, d_img, (long long)stride, h, w, lb, eps, \
+                                        d_out, (long long)out_stride)
+                switch (cn) {
+                case 1: FG_LAUNCH(1); break;
+                case 2: FG_LAUNCH(2); break;
+                case 3: FG_LAUNCH(3); break;
+                default: FG_LAUNCH(4); break;
+                }
+#undef FG_LAUNCH
             }
             return check_launch("guided_fused");
         }
