@@ -4547,6 +4547,157 @@ __global__ __launch_bounds__(256) void k_resize_gray_pair_tall(const unsigned ch
     if (tid == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
 }
 
+// Round 3: the sampler for gentle down-sampling as a COLUMN MARCH.  cv2's INTER_CUBIC on u8 is exact integer arithmetic and
+// separable -- sum_t cy[t] * (sum_k cx[k] * s[t][k]) -- so a lane that owns one destination column walks down the source
+// rows, forms the horizontal 4-tap sums of each row ONCE (both images, three channels; a row feeds the 1.6 destination rows
+// whose windows contain it), keeps the last four rows' sums in registers and finishes a destination pixel whenever the row
+// just pushed is a window's last.  The byte pairs are formed with v_perm_b32 and multiplied with v_dot2_i32_i16 (two taps
+// per instruction: the coefficients are 16-bit): ~150 VALU instructions per destination pixel instead of ~270.
+// A wave owns RGM_SEG destination rows of 64 columns and is autonomous -- no block barrier.  The source rows reach the lanes
+// through a WAVE-PRIVATE LDS window: the wave copies the contiguous span of each row it needs with aligned 16-byte loads
+// (five or six cache-line accesses per row) and every lane then picks its 12 bytes from LDS.  Letting each lane load its own
+// unaligned 12 bytes from global memory was measured first: 49 L1 accesses per wave instruction (TCP_TOTAL_CACHE_ACCESSES /
+// TA_FLAT_READ_WAVEFRONTS), the L1 tag pipeline 75 % busy, 0.49 ms at x0.4.  The next group's rows are requested before the
+// current group is processed.  Same integers as cubic_sample.
+#ifndef RGM_SEG
+#define RGM_SEG 16
+#endif
+typedef short rg_s2_t __attribute__((ext_vector_type(2)));
+
+// horizontal 4-tap sums of one row's 12 bytes (4 pixels x RGB): hs[c] = sum_k px[k][c] * cx[k]
+__device__ __forceinline__ void rgm_hrow(unsigned q0, unsigned q1, unsigned q2, rg_s2_t c01, rg_s2_t c23, int (&hs)[3])
+{
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        // bytes c and 3 + c of (q0, q1); bytes 6 + c and 9 + c of (q1, q2), each zero-extended to 16 bits
+        const unsigned pa = __builtin_amdgcn_perm(q1, q0, 0x0c000c00u | (unsigned)c | ((unsigned)(3 + c) << 16));
+        const unsigned pb = __builtin_amdgcn_perm(q2, q1, 0x0c000c00u | (unsigned)(2 + c) | ((unsigned)(5 + c) << 16));
+        hs[c] = __builtin_amdgcn_sdot2(__builtin_bit_cast(rg_s2_t, pa), c01,
+                                       __builtin_amdgcn_sdot2(__builtin_bit_cast(rg_s2_t, pb), c23, 0, false), false);
+    }
+}
+
+// the 16-byte chunk `ck` of a source row's window (never reads past the row)
+__device__ __forceinline__ u4_t rgm_load_chunk(const unsigned char *__restrict__ row, int off, int rowbytes)
+{
+    if (off + 16 <= rowbytes) return *(const __attribute__((address_space(1))) u4_a1_t *)(row + off);
+    unsigned w4[4] = {0u, 0u, 0u, 0u};
+    for (int i = 0; i < 16 && off + i < rowbytes; ++i) w4[i >> 2] |= (unsigned)row[off + i] << (8 * (i & 3));
+    u4_t v;
+    v.x = w4[0]; v.y = w4[1]; v.z = w4[2]; v.w = w4[3];
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_resize_gray_pair_march(const unsigned char *__restrict__ a, long long sa,
+                                                                const unsigned char *__restrict__ b, long long sb, int sh, int sw,
+                                                                const CubicTab *__restrict__ xt, const CubicTab *__restrict__ yt,
+                                                                int dh, int dw, int shift, unsigned char *__restrict__ ga,
+                                                                unsigned char *__restrict__ gb, long long pitch, int lds_pitch,
+                                                                double *__restrict__ part)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char win[];      // [wave 4][image 2][row 4][lds_pitch]
+    __shared__ double ws[4];
+    const int tx = threadIdx.x, tid = threadIdx.y * 64 + tx;
+    const int bx0 = blockIdx.x * 64, x = bx0 + tx;
+    const int ys = __builtin_amdgcn_readfirstlane((blockIdx.y * 4 + threadIdx.y) * RGM_SEG), ye = min(ys + RGM_SEG, dh);
+    unsigned sse = 0;
+    if (ys < dh) {                                                  // wave-uniform
+        unsigned char *mine = win + (size_t)threadIdx.y * 8 * lds_pitch;
+        const int c_lo = max(xt[bx0].ofs - 1, 0), c_hi = min(xt[min(bx0 + 63, dw - 1)].ofs + 2, sw - 1);
+        const int byte0 = (c_lo * 3) & ~15, nchunk = ((c_hi + 1) * 3 - byte0 + 15) >> 4, rowbytes = sw * 3;   // nchunk <= 64 (host)
+        const CubicTab X = xt[min(x, dw - 1)];                      // lanes past the end repeat the last column, store nothing
+        const bool inner = X.ofs - 1 >= 0 && X.ofs + 2 <= sw - 1;
+        const int loff = max(X.ofs - 1, 0) * 3 - byte0;             // this lane's 12 bytes inside the window
+        rg_s2_t c01, c23;
+        c01.x = X.c[0]; c01.y = X.c[1]; c23.x = X.c[2]; c23.y = X.c[3];
+        int y = ys, yofs = yt[ys].ofs;
+        const int r_end = yt[ye - 1].ofs + 2;
+        int ha[4][3], hb[4][3];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) ha[p][c] = hb[p][c] = 0;
+        u4_t va4[4], vb4[4];                                        // the rows in flight (lane = chunk)
+        auto request = [&](int r) {                                 // unclamped row numbers: rows beyond the image repeat the edge
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int sr = min(max(r + p, 0), sh - 1);
+                if (tx < nchunk) {
+                    va4[p] = rgm_load_chunk(a + (size_t)sr * sa, byte0 + 16 * tx, rowbytes);
+                    vb4[p] = rgm_load_chunk(b + (size_t)sr * sb, byte0 + 16 * tx, rowbytes);
+                }
+            }
+        };
+        request(yofs - 1);
+        for (int r = yofs - 1; r <= r_end; r += 4) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the previous group's LDS reads are done
+            __builtin_amdgcn_wave_barrier();
+            if (tx < nchunk) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    *(u4_t *)(mine + (size_t)p * lds_pitch + 16 * tx) = va4[p];
+                    *(u4_t *)(mine + (size_t)(4 + p) * lds_pitch + 16 * tx) = vb4[p];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (r + 4 <= r_end) request(r + 4);                     // flies under this group's arithmetic
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if (r + p <= r_end) {                               // wave-uniform
+                    const unsigned char *ra = mine + (size_t)p * lds_pitch, *rb = mine + (size_t)(4 + p) * lds_pitch;
+                    unsigned wa[3], wb[3];
+                    if (inner) {
+                        lds_tap12(ra, loff, wa);
+                        lds_tap12(rb, loff, wb);
+                    } else {                                        // image border columns: taps clamped one by one
+                        wa[0] = wa[1] = wa[2] = wb[0] = wb[1] = wb[2] = 0u;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int sx = min(max(X.ofs + k - 1, 0), sw - 1) * 3 - byte0;
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) {
+                                const int i = 3 * k + c;
+                                wa[i >> 2] |= (unsigned)ra[sx + c] << (8 * (i & 3));
+                                wb[i >> 2] |= (unsigned)rb[sx + c] << (8 * (i & 3));
+                            }
+                        }
+                    }
+                    rgm_hrow(wa[0], wa[1], wa[2], c01, c23, ha[p]);
+                    rgm_hrow(wb[0], wb[1], wb[2], c01, c23, hb[p]);
+                    if (y < ye && yofs + 2 == r + p) {              // this row completes the window of destination row y
+                        const CubicTab Y = yt[y];
+                        int va[3], vb[3];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            int s0 = 1 << 21, s1 = 1 << 21;
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {           // tap t = row r + p - 3 + t = ring slot (p + 1 + t) & 3
+                                s0 += ha[(p + 1 + t) & 3][c] * (int)Y.c[t];
+                                s1 += hb[(p + 1 + t) & 3][c] * (int)Y.c[t];
+                            }
+                            va[c] = min(max(s0 >> 22, 0), 255);
+                            vb[c] = min(max(s1 >> 22, 0), 255);
+                        }
+                        if (x < dw) {
+                            ga[(size_t)y * pitch + x] = (unsigned char)gray_rgb(va[0], va[1], va[2], shift);
+                            gb[(size_t)y * pitch + x] = (unsigned char)gray_rgb(vb[0], vb[1], vb[2], shift);
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) sse += (unsigned)((va[c] - vb[c]) * (va[c] - vb[c]));
+                        }
+                        ++y;
+                        yofs = y < ye ? yt[y].ofs : 0x3fffffff;
+                    }
+                }
+            }
+        }
+    }
+    const double sred = wave_sum_f64((double)sse);
+    if ((tid & 63) == 0) ws[tid >> 6] = sred;
+    __syncthreads();
+    if (tid == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
 __global__ void k_store_sse(const double *__restrict__ src, sr_assess_sums *__restrict__ out)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) out->sse = src[0];
@@ -4843,8 +4994,11 @@ int sr_assess_resized_u8_async(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a
         }
         if (mr * 4 <= 16 * RGT_ROWS * 3 && (size_t)2 * mr * lds_pitch <= 64 * 1024) tall_rows = mr;
     }
+    // ... and since round 3 the same condition selects the LDS-free column march instead (SR_RESIZE_MARCH=0: the staged kernel)
+    const bool march = tall_rows > 0 && lds_pitch <= 64 * 16 && !(std::getenv("SR_RESIZE_MARCH") && std::getenv("SR_RESIZE_MARCH")[0] == '0');
     const dim3 block(64, 4), grid(lds_pitch ? (unsigned)((dst_w + 63) / 64) : (unsigned)((dst_w + 255) / 256),
-                                 tall_rows ? (unsigned)((dst_h + 4 * RGT_ROWS - 1) / (4 * RGT_ROWS)) : (unsigned)((dst_h + 3) / 4));
+                                 march ? (unsigned)((dst_h + 4 * RGM_SEG - 1) / (4 * RGM_SEG))
+                                 : tall_rows ? (unsigned)((dst_h + 4 * RGT_ROWS - 1) / (4 * RGT_ROWS)) : (unsigned)((dst_h + 3) / 4));
     const size_t nblk = (size_t)grid.x * grid.y, plane = (size_t)pitch * dst_h;
     const size_t off_part = (2 * plane + 255) / 256 * 256, need = off_part + (nblk + 2 * (nblk / 1024 + 2)) * sizeof(double);
     if (need > ctx->gray_planes_bytes) {
@@ -4863,7 +5017,10 @@ int sr_assess_resized_u8_async(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a
     const double *sse_ptr = nullptr;
     {
         ProfScope ps(ctx, "resize_gray");
-        if (tall_rows) {
+        if (march) {
+            hipLaunchKernelGGL(k_resize_gray_pair_march, grid, block, (size_t)32 * lds_pitch, ctx->stream, d_a, (long long)stride_a, d_b,
+                               (long long)stride_b, h, w, d_xt, d_yt, dst_h, dst_w, gray_shift, ga, gb, (long long)pitch, lds_pitch, part);
+        } else if (tall_rows) {
             {
                 static std::mutex mu2;
                 static std::set<int> done2;

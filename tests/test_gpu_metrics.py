@@ -150,7 +150,11 @@ def test_tile_extract_pad_iterated_reflection(ctx, rng):
 
 
 @pytest.mark.parametrize("shape,dst", [((300, 411, 3), (111, 152)), ((193, 257, 3), (19, 25)), ((128, 640), (51, 256)),
-                                         ((97, 83, 3), (97, 83)), ((64, 64, 3), (5, 6))])
+                                         ((97, 83, 3), (97, 83)), ((64, 64, 3), (5, 6)),
+                                         # gentle down-sampling (the LDS-free column march, k_resize_gray_pair_march): ragged
+                                         # segments of 16 rows / 64 columns, border columns, scales 0.3 .. 0.9
+                                         ((257, 300, 3), (129, 151)), ((100, 700, 3), (77, 333)), ((333, 90, 3), (100, 81)),
+                                         ((70, 200, 3), (65, 66))])
 def test_assess_resized_equals_resize_then_assess(ctx, rng, shape, dst):
     """sr_assess_resized_u8 (bicubic resize sampled on the fly inside the metric kernel) gives the
     sums of sr_resize_cubic_u8 on both images followed by sr_assess_u8 -- and those of the oracle's resize + metrics."""
