@@ -4577,18 +4577,23 @@ __device__ __forceinline__ void rgm_hrow(unsigned q0, unsigned q1, unsigned q2, 
     }
 }
 
-// the 16-byte chunk `ck` of a source row's window (never reads past the row)
-__device__ __forceinline__ u4_t rgm_load_chunk(const unsigned char *__restrict__ row, int off, int rowbytes)
+// one 16-byte chunk of a source row's window.  A chunk that crosses the end of its row reads on into the next row (bytes
+// no tap uses); only on the image's LAST row would that leave the buffer, and there the bytes are fetched one by one.
+__device__ __forceinline__ u4_t rgm_load_chunk(const unsigned char *__restrict__ row, int off, int rowbytes, bool last_row)
 {
-    if (off + 16 <= rowbytes) return *(const __attribute__((address_space(1))) u4_a1_t *)(row + off);
+    if (!last_row || off + 16 <= rowbytes) return *(const __attribute__((address_space(1))) u4_a1_t *)(row + off);
     unsigned w4[4] = {0u, 0u, 0u, 0u};
+#pragma unroll 1
     for (int i = 0; i < 16 && off + i < rowbytes; ++i) w4[i >> 2] |= (unsigned)row[off + i] << (8 * (i & 3));
     u4_t v;
     v.x = w4[0]; v.y = w4[1]; v.z = w4[2]; v.w = w4[3];
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_resize_gray_pair_march(const unsigned char *__restrict__ a, long long sa,
+#ifndef RGM_MINB
+#define RGM_MINB 5
+#endif
+__global__ __launch_bounds__(256, RGM_MINB) void k_resize_gray_pair_march(const unsigned char *__restrict__ a, long long sa,
                                                                 const unsigned char *__restrict__ b, long long sb, int sh, int sw,
                                                                 const CubicTab *__restrict__ xt, const CubicTab *__restrict__ yt,
                                                                 int dh, int dw, int shift, unsigned char *__restrict__ ga,
@@ -4623,13 +4628,25 @@ __global__ __launch_bounds__(256) void k_resize_gray_pair_march(const unsigned c
             for (int p = 0; p < 4; ++p) {
                 const int sr = min(max(r + p, 0), sh - 1);
                 if (tx < nchunk) {
-                    va4[p] = rgm_load_chunk(a + (size_t)sr * sa, byte0 + 16 * tx, rowbytes);
-                    vb4[p] = rgm_load_chunk(b + (size_t)sr * sb, byte0 + 16 * tx, rowbytes);
+                    va4[p] = rgm_load_chunk(a + (size_t)sr * sa, byte0 + 16 * tx, rowbytes, sr == sh - 1);
+                    vb4[p] = rgm_load_chunk(b + (size_t)sr * sb, byte0 + 16 * tx, rowbytes, sr == sh - 1);
                 }
             }
         };
         request(yofs - 1);
-        for (int r = yofs - 1; r <= r_end; r += 4) {
+        for (int r = yofs - 1, r_next; r <= r_end; r = r_next) {
+            // where the next group of four rows starts: right below this one, or -- when the windows lie further apart than
+            // four rows (scales below 0.25) -- at the first row of the next window still to be finished (scalar bookkeeping)
+            {
+                int yn = y, yo = yofs;
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    if (yn < ye && yo + 2 == r + p) {
+                        ++yn;
+                        yo = yn < ye ? yt[yn].ofs : 0x3fffffff;
+                    }
+                r_next = yn < ye ? max(r + 4, yo - 1) : r_end + 1;
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the previous group's LDS reads are done
             __builtin_amdgcn_wave_barrier();
             if (tx < nchunk) {
@@ -4641,7 +4658,7 @@ __global__ __launch_bounds__(256) void k_resize_gray_pair_march(const unsigned c
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (r + 4 <= r_end) request(r + 4);                     // flies under this group's arithmetic
+            if (r_next <= r_end) request(r_next);                   // flies under this group's arithmetic
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 if (r + p <= r_end) {                               // wave-uniform
@@ -4994,8 +5011,9 @@ int sr_assess_resized_u8_async(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a
         }
         if (mr * 4 <= 16 * RGT_ROWS * 3 && (size_t)2 * mr * lds_pitch <= 64 * 1024) tall_rows = mr;
     }
-    // ... and since round 3 the same condition selects the LDS-free column march instead (SR_RESIZE_MARCH=0: the staged kernel)
-    const bool march = tall_rows > 0 && lds_pitch <= 64 * 16 && !(std::getenv("SR_RESIZE_MARCH") && std::getenv("SR_RESIZE_MARCH")[0] == '0');
+    // since round 3 the wave-autonomous column march (k_resize_gray_pair_march) takes every down-sampling whose 64-column source
+    // window is at most 64 chunks of 16 bytes, i.e. scales down to about 0.19 (SR_RESIZE_MARCH=0: the block-staged kernels)
+    const bool march = lds_pitch > 0 && lds_pitch <= 64 * 16 + 16 && !(std::getenv("SR_RESIZE_MARCH") && std::getenv("SR_RESIZE_MARCH")[0] == '0');
     const dim3 block(64, 4), grid(lds_pitch ? (unsigned)((dst_w + 63) / 64) : (unsigned)((dst_w + 255) / 256),
                                  march ? (unsigned)((dst_h + 4 * RGM_SEG - 1) / (4 * RGM_SEG))
                                  : tall_rows ? (unsigned)((dst_h + 4 * RGT_ROWS - 1) / (4 * RGT_ROWS)) : (unsigned)((dst_h + 3) / 4));
