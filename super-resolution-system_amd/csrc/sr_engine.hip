@@ -4473,100 +4473,6 @@ __global__ __launch_bounds__(256) void k_resize_gray_pair_lds(const unsigned cha
     if (tid == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
 }
 
-// The same sampler for gentle down-sampling (scale above ~0.25: the four tap rows of consecutive destination rows
-// overlap): a block owns 64 x 16 destination pixels and stages every SOURCE row between its first and last tap ONCE
-// (about 43 rows per image at x0.4, where four destination rows at a time reload 64 for the same 16), each thread samples
-// four destination rows of its column.  Same integers as cubic_sample.
-#define RGT_ROWS 4                       /* destination rows per thread: a block covers 4 * RGT_ROWS of them */
-__global__ __launch_bounds__(256) void k_resize_gray_pair_tall(const unsigned char *__restrict__ a, long long sa,
-                                                               const unsigned char *__restrict__ b, long long sb, int sh, int sw,
-                                                               const CubicTab *__restrict__ xt, const CubicTab *__restrict__ yt,
-                                                               int dh, int dw, int shift, unsigned char *__restrict__ ga,
-                                                               unsigned char *__restrict__ gb, long long pitch, int lds_pitch,
-                                                               int max_rows, double *__restrict__ part)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char win[];      // [image 2][row max_rows][lds_pitch]
-    __shared__ double ws[4];
-    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
-    const int bx0 = blockIdx.x * 64, by0 = blockIdx.y * (4 * RGT_ROWS);
-    const int xl = bx0, xr = min(bx0 + 63, dw - 1);
-    const int c_lo = max(xt[xl].ofs - 1, 0), c_hi = min(xt[xr].ofs + 2, sw - 1);
-    const int byte0 = (c_lo * 3) & ~15, nbytes = (c_hi + 1) * 3 - byte0;
-    const int nchunk = (nbytes + 15) >> 4, rowbytes = sw * 3;
-    const int r_lo = max(yt[by0].ofs - 1, 0), r_hi = min(yt[min(by0 + 4 * RGT_ROWS - 1, dh - 1)].ofs + 2, sh - 1);
-    const int n_rows = min(r_hi - r_lo + 1, max_rows);                      // host sizes max_rows: never clipped
-    for (int e = tid; e < 2 * n_rows * nchunk; e += 256) {
-        const int rr = e / nchunk, ck = e - rr * nchunk;                    // rr = image * n_rows + row
-        const int img = rr >= n_rows ? 1 : 0, row = rr - img * n_rows;
-        const unsigned char *src = (img ? b + (size_t)(r_lo + row) * sb : a + (size_t)(r_lo + row) * sa);
-        const int off = byte0 + 16 * ck;
-        u4_t v;
-        if (off + 16 <= rowbytes) {
-            v = *(const __attribute__((address_space(1))) u4_a1_t *)(src + off);
-        } else {
-            unsigned w4[4] = {0u, 0u, 0u, 0u};
-            for (int i = 0; i < 16 && off + i < rowbytes; ++i) w4[i >> 2] |= (unsigned)src[off + i] << (8 * (i & 3));
-            v.x = w4[0]; v.y = w4[1]; v.z = w4[2]; v.w = w4[3];
-        }
-        *(u4_t *)(win + ((size_t)img * max_rows + row) * lds_pitch + 16 * ck) = v;
-    }
-    __syncthreads();
-    const int x = bx0 + tx;
-    unsigned sse = 0;
-    if (x < dw) {
-        const CubicTab X = xt[x];
-        const bool inner = X.ofs - 1 >= 0 && X.ofs + 2 <= sw - 1;
-#pragma unroll 1
-        for (int j = 0; j < RGT_ROWS; ++j) {
-            const int y = by0 + ty * RGT_ROWS + j;
-            if (y >= dh) break;
-            const CubicTab Y = yt[y];
-            int va[3], vb[3];
-#pragma unroll
-            for (int img = 0; img < 2; ++img) {
-                int acc[3] = {0, 0, 0};
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int srow = min(max(Y.ofs - 1 + t, 0), sh - 1) - r_lo;
-                    const unsigned char *row = win + ((size_t)img * max_rows + srow) * lds_pitch;
-                    int v[4][3];
-                    if (inner) {
-                        unsigned wd[3];
-                        lds_tap12(row, (X.ofs - 1) * 3 - byte0, wd);
-#pragma unroll
-                        for (int q = 0; q < 12; ++q) v[q / 3][q % 3] = (int)((wd[q >> 2] >> (8 * (q & 3))) & 0xFFu);
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const int sx = min(max(X.ofs + k - 1, 0), sw - 1) * 3 - byte0;
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) v[k][c] = (int)row[sx + c];
-                        }
-                    }
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const int hs = v[0][c] * X.c[0] + v[1][c] * X.c[1] + v[2][c] * X.c[2] + v[3][c] * X.c[3];
-                        acc[c] += hs * (int)Y.c[t];
-                    }
-                }
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const int r = (acc[c] + (1 << 21)) >> 22;
-                    (img ? vb : va)[c] = r < 0 ? 0 : (r > 255 ? 255 : r);
-                }
-            }
-            ga[(size_t)y * pitch + x] = (unsigned char)gray_rgb(va[0], va[1], va[2], shift);
-            gb[(size_t)y * pitch + x] = (unsigned char)gray_rgb(vb[0], vb[1], vb[2], shift);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) sse += (unsigned)((va[c] - vb[c]) * (va[c] - vb[c]));
-        }
-    }
-    const double sred = wave_sum_f64((double)sse);
-    if ((tid & 63) == 0) ws[tid >> 6] = sred;
-    __syncthreads();
-    if (tid == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
-}
-
 // Round 3: the sampler for gentle down-sampling as a COLUMN MARCH.  cv2's INTER_CUBIC on u8 is exact integer arithmetic and
 // separable -- sum_t cy[t] * (sum_k cx[k] * s[t][k]) -- so a lane that owns one destination column walks down the source
 // rows, forms the horizontal 4-tap sums of each row ONCE (both images, three channels; a row feeds the 1.6 destination rows
@@ -4618,19 +4524,22 @@ __global__ __launch_bounds__(256, RGM_MINB) void k_resize_gray_pair_march(const 
                                                                 const CubicTab *__restrict__ xt, const CubicTab *__restrict__ yt,
                                                                 int dh, int dw, int shift, unsigned char *__restrict__ ga,
                                                                 unsigned char *__restrict__ gb, long long pitch, int lds_pitch,
-                                                                double *__restrict__ part)
+                                                                int cols, double *__restrict__ part)
 {
+    // cols = destination columns per wave: 64, or 32 for scales below 0.19 whose 64-column window would exceed the 64
+    // chunks a wave loads per row (all 64 lanes still load; the upper 32 sample a repeated column and store nothing -- at
+    // those scales the kernel is bound by its loads, there are 25 x fewer destination than source pixels)
     extern __shared__ __attribute__((aligned(16))) unsigned char win[];      // [wave 4][image 2][row 4][lds_pitch]
     __shared__ double ws[4];
     const int tx = threadIdx.x, tid = threadIdx.y * 64 + tx;
-    const int bx0 = blockIdx.x * 64, x = bx0 + tx;
+    const int bx0 = blockIdx.x * cols, x = tx < cols ? bx0 + tx : dw;
     const int ys = __builtin_amdgcn_readfirstlane((blockIdx.y * 4 + threadIdx.y) * RGM_SEG), ye = min(ys + RGM_SEG, dh);
     unsigned sse = 0;
     if (ys < dh) {                                                  // wave-uniform
         unsigned char *mine = win + (size_t)threadIdx.y * 8 * lds_pitch;
-        const int c_lo = max(xt[bx0].ofs - 1, 0), c_hi = min(xt[min(bx0 + 63, dw - 1)].ofs + 2, sw - 1);
+        const int c_lo = max(xt[bx0].ofs - 1, 0), c_hi = min(xt[min(bx0 + cols - 1, dw - 1)].ofs + 2, sw - 1);
         const int byte0 = (c_lo * 3) & ~15, nchunk = ((c_hi + 1) * 3 - byte0 + 15) >> 4, rowbytes = sw * 3;   // nchunk <= 64 (host)
-        const CubicTab X = xt[min(x, dw - 1)];                      // lanes past the end repeat the last column, store nothing
+        const CubicTab X = xt[min(x, min(bx0 + cols, dw) - 1)];     // lanes past the end repeat the wave's last column, store nothing
         const bool inner = X.ofs - 1 >= 0 && X.ofs + 2 <= sw - 1;
         const int loff = max(X.ofs - 1, 0) * 3 - byte0;             // this lane's 12 bytes inside the window
         rg_s2_t c01, c23;
@@ -5010,33 +4919,30 @@ int sr_assess_resized_u8_async(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a
     const CubicTab *d_xt = (const CubicTab *)ctx->resize_tab.d, *d_yt = d_xt + dst_w;
     const int64_t pitch = ((int64_t)dst_w + 63) / 64 * 64;
     // down-sampling RGB: the LDS-staged kernel when its source window (64 destination columns wide) fits
-    int lds_pitch = 0;
+    int lds_pitch = 0, march_cols = 0, march_pitch = 0;
     if (cn == 3 && dst_w < w && dst_h < h) {
-        int span = 0;
-        for (int x0b = 0; x0b < dst_w; x0b += 64) {
-            const int lo = std::max(xt[(size_t)x0b].ofs - 1, 0), hi = std::min(xt[(size_t)std::min(x0b + 63, dst_w - 1)].ofs + 2, w - 1);
-            span = std::max(span, (hi + 1) * 3 - ((lo * 3) & ~15));
-        }
-        const int lp = (span + 15) / 16 * 16 + 16;                                 // + one chunk: lds_tap12 reads 16 aligned bytes
+        auto window_pitch = [&](int cols) {
+            int span = 0;
+            for (int x0b = 0; x0b < dst_w; x0b += cols) {
+                const int lo = std::max(xt[(size_t)x0b].ofs - 1, 0), hi = std::min(xt[(size_t)std::min(x0b + cols - 1, dst_w - 1)].ofs + 2, w - 1);
+                span = std::max(span, (hi + 1) * 3 - ((lo * 3) & ~15));
+            }
+            return (span + 15) / 16 * 16 + 16;                                     // + one chunk: lds_tap12 reads 16 aligned bytes
+        };
+        const int lp = window_pitch(64);
         if (32 * lp <= 64 * 1024) lds_pitch = lp;
-    }
-    // gentle down-sampling: blocks of 16 destination rows that stage each source row once (k_resize_gray_pair_tall), when
-    // that is at least a quarter fewer rows than the 4 rows x 4 taps layout loads and the window fits 64 KB
-    int tall_rows = 0;
-    if (lds_pitch) {
-        int mr = 0;
-        for (int y0b = 0; y0b < dst_h; y0b += 4 * RGT_ROWS) {
-            const int lo = std::max(yt[(size_t)y0b].ofs - 1, 0), hi = std::min(yt[(size_t)std::min(y0b + 4 * RGT_ROWS - 1, dst_h - 1)].ofs + 2, h - 1);
-            mr = std::max(mr, hi - lo + 1);
+        for (int cols = 64; cols >= 32 && !march_cols; cols >>= 1) {
+            const int mp = cols == 64 ? lp : window_pitch(cols);
+            if (mp <= 64 * 16 + 16) { march_cols = cols; march_pitch = mp; }
         }
-        if (mr * 4 <= 16 * RGT_ROWS * 3 && (size_t)2 * mr * lds_pitch <= 64 * 1024) tall_rows = mr;
     }
-    // since round 3 the wave-autonomous column march (k_resize_gray_pair_march) takes every down-sampling whose 64-column source
-    // window is at most 64 chunks of 16 bytes, i.e. scales down to about 0.19 (SR_RESIZE_MARCH=0: the block-staged kernels)
-    const bool march = lds_pitch > 0 && lds_pitch <= 64 * 16 + 16 && !(std::getenv("SR_RESIZE_MARCH") && std::getenv("SR_RESIZE_MARCH")[0] == '0');
-    const dim3 block(64, 4), grid(lds_pitch ? (unsigned)((dst_w + 63) / 64) : (unsigned)((dst_w + 255) / 256),
-                                 march ? (unsigned)((dst_h + 4 * RGM_SEG - 1) / (4 * RGM_SEG))
-                                 : tall_rows ? (unsigned)((dst_h + 4 * RGT_ROWS - 1) / (4 * RGT_ROWS)) : (unsigned)((dst_h + 3) / 4));
+    // since round 3 the wave-autonomous column march (k_resize_gray_pair_march) takes every down-sampling whose source window
+    // (64 destination columns wide, or 32) is at most 64 chunks of 16 bytes, i.e. scales down to about 0.095
+    // (SR_RESIZE_MARCH=0: the block-staged kernel)
+    const bool march = march_cols > 0 && !(std::getenv("SR_RESIZE_MARCH") && std::getenv("SR_RESIZE_MARCH")[0] == '0');
+    const dim3 block(64, 4), grid(march ? (unsigned)((dst_w + march_cols - 1) / march_cols)
+                                 : lds_pitch ? (unsigned)((dst_w + 63) / 64) : (unsigned)((dst_w + 255) / 256),
+                                 march ? (unsigned)((dst_h + 4 * RGM_SEG - 1) / (4 * RGM_SEG)) : (unsigned)((dst_h + 3) / 4));
     const size_t nblk = (size_t)grid.x * grid.y, plane = (size_t)pitch * dst_h;
     const size_t off_part = (2 * plane + 255) / 256 * 256, need = off_part + (nblk + 2 * (nblk / 1024 + 2)) * sizeof(double);
     if (need > ctx->gray_planes_bytes) {
@@ -5056,21 +4962,9 @@ int sr_assess_resized_u8_async(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a
     {
         ProfScope ps(ctx, "resize_gray");
         if (march) {
-            hipLaunchKernelGGL(k_resize_gray_pair_march, grid, block, (size_t)32 * lds_pitch, ctx->stream, d_a, (long long)stride_a, d_b,
-                               (long long)stride_b, h, w, d_xt, d_yt, dst_h, dst_w, gray_shift, ga, gb, (long long)pitch, lds_pitch, part);
-        } else if (tall_rows) {
-            {
-                static std::mutex mu2;
-                static std::set<int> done2;
-                std::lock_guard<std::mutex> lk(mu2);
-                if (!done2.count(ctx->device)) {
-                    HIPCHK(hipFuncSetAttribute((const void *)k_resize_gray_pair_tall, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-                    done2.insert(ctx->device);
-                }
-            }
-            hipLaunchKernelGGL(k_resize_gray_pair_tall, grid, block, (size_t)2 * tall_rows * lds_pitch, ctx->stream, d_a, (long long)stride_a,
-                               d_b, (long long)stride_b, h, w, d_xt, d_yt, dst_h, dst_w, gray_shift, ga, gb, (long long)pitch, lds_pitch,
-                               tall_rows, part);
+            hipLaunchKernelGGL(k_resize_gray_pair_march, grid, block, (size_t)32 * march_pitch, ctx->stream, d_a, (long long)stride_a, d_b,
+                               (long long)stride_b, h, w, d_xt, d_yt, dst_h, dst_w, gray_shift, ga, gb, (long long)pitch, march_pitch,
+                               march_cols, part);
         } else if (lds_pitch) {
             {   // once per device (the attribute belongs to the function ON a device), under a lock: contexts of several
                 // devices / threads reach this concurrently

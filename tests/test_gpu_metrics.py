@@ -156,7 +156,9 @@ def test_tile_extract_pad_iterated_reflection(ctx, rng):
                                          ((257, 300, 3), (129, 151)), ((100, 700, 3), (77, 333)), ((333, 90, 3), (100, 81)),
                                          ((70, 200, 3), (65, 66)),
                                          # windows further apart than four rows (the march jumps), mixed steps around 4
-                                         ((400, 330, 3), (80, 66)), ((391, 345, 3), (100, 90)), ((300, 640, 3), (61, 128))])
+                                         ((400, 330, 3), (80, 66)), ((391, 345, 3), (100, 90)), ((300, 640, 3), (61, 128)),
+                                         # scales near 0.1: 32 destination columns per wave
+                                         ((600, 1000, 3), (60, 100)), ((410, 777, 3), (50, 90))])
 def test_assess_resized_equals_resize_then_assess(ctx, rng, shape, dst):
     """sr_assess_resized_u8 (bicubic resize sampled on the fly inside the metric kernel) gives the
     sums of sr_resize_cubic_u8 on both images followed by sr_assess_u8 -- and those of the oracle's resize + metrics."""
