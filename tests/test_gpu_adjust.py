@@ -134,5 +134,8 @@ def test_color_correction_ximgproc_branch(rng, method):
     tiny = _scene(rng, 6, 9)
     assert np.array_equal(bx.color_correction(tiny, tiny[::-1].copy(), method=method),
                           onp.color_correction(tiny, tiny[::-1].copy(), method=method, guided="ximgproc"))
+    wide = _scene(rng, 130, 256)                                 # width a multiple of 4: the 17 x 17 box kernel's interior blocks
+    assert np.array_equal(bx.color_correction(wide, ref, method=method),
+                          onp.color_correction(wide, ref, method=method, guided="ximgproc"))
     with pytest.raises(ValueError):
         BlendingModule(guided_filter="bilateral")
