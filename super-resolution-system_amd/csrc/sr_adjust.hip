@@ -793,6 +793,74 @@ __global__ __launch_bounds__(256) void k_gf_box17(const float *__restrict__ A, c
     }
 }
 
+// Second stage of the colour guided filter for one source channel in ONE launch: the 17 x 17 box means of a_0, a_1, a_2 and b
+// (the planes ab[first], ab[first + 1], ab[first + 2], ab[bplane]) formed one after the other with k_gf_box17's passes, the
+// eight means per map of a thread kept in registers, then q = ((mean_a0 * I_0 + mean_a1 * I_1) + mean_a2 * I_2) + mean_b ->
+// clip -> truncate.  Replaces four box launches + a quarter of k_gf_out: the twelve mean planes are never written.
+__global__ __launch_bounds__(256) void k_gf_box17_out(const float *__restrict__ ab, const float *__restrict__ planes, size_t plane,
+                                                      int first, int bplane, int h, int w, double scale, int c,
+                                                      unsigned char *__restrict__ out, long long ostride)
+{
+    __shared__ __attribute__((aligned(16))) float pt[GB_PH * GB_PW];
+    __shared__ __attribute__((aligned(16))) double hs[GB_PH * GB_TW];
+    const int tid = threadIdx.x, anchor = GB_R / 2;
+    const int x0 = blockIdx.x * GB_TW, y0 = blockIdx.y * GB_TH;
+    const bool inner = (w & 3) == 0 && x0 >= anchor && x0 - anchor + GB_PW <= w && y0 >= anchor && y0 - anchor + GB_PH <= h;
+    const int l = tid & 63, g = tid >> 6, ox = 4 * (l & 15) + (l >> 4);
+    const int x = x0 + ox;
+    float acc[8];                                                 // the output expression, built left to right as the means arrive
+#pragma unroll 1
+    for (int m = 0; m < 4; ++m) {
+        const float *A = ab + (size_t)(m < 3 ? first + m : bplane) * plane;
+        if (inner) {
+            for (int e = tid; e < GB_PH * (GB_PW / 4); e += 256) {
+                const int py = e / (GB_PW / 4), q = e - py * (GB_PW / 4);
+                *(float4 *)(pt + py * GB_PW + 4 * q) = *(const float4 *)(A + (size_t)(y0 + py - anchor) * w + (x0 - anchor) + 4 * q);
+            }
+        } else {
+            for (int e = tid; e < GB_PH * GB_PW; e += 256) {
+                const int py = e / GB_PW, px = e - py * GB_PW;
+                pt[e] = A[(size_t)gf_reflect(y0 + py - anchor, h) * w + gf_reflect(x0 + px - anchor, w)];
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < GB_PH * 16; e += 256) {
+            const int py = e >> 4, gx = e & 15;
+            const float4 *r = (const float4 *)(pt + py * GB_PW + 4 * gx);
+            const float4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3], q4 = r[4];
+            const double v[20] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z, q4.w};
+            double o[4];
+            gb_sums<4, 20>(v, o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hs[py * GB_TW + j * 16 + gx] = o[j];
+        }
+        __syncthreads();
+        {
+            double v[24], o[8];
+#pragma unroll
+            for (int k = 0; k < 24; ++k) v[k] = hs[(8 * g + k) * GB_TW + l];
+            gb_sums<8, 24>(v, o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float mean = (float)(o[j] * scale);
+                const int y = min(y0 + 8 * g + j, h - 1);
+                const float gi = m < 3 ? planes[(size_t)m * plane + (size_t)y * w + min(x, w - 1)] : 0.0f;
+                acc[j] = m == 0 ? mean * gi : (m < 3 ? acc[j] + mean * gi : acc[j] + mean);
+            }
+        }
+        __syncthreads();                                          // pt / hs are free for the next map
+    }
+    if (x >= w) return;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int y = y0 + 8 * g + j;
+        if (y >= h) break;
+        const float r = acc[j];
+        const float cl = r < 0.0f ? 0.0f : (r > 255.0f ? 255.0f : r);
+        out[(size_t)y * ostride + (size_t)x * 3 + c] = (unsigned char)cl;
+    }
+}
+
 // per pixel: the linear coefficients.  means: [0..2] mI, [3..8] mII (00 01 02 11 12 22), [9..11] mp, [12..20] mIp (c * 3 + i).
 // out: [c * 3 + i] a_ci, [9 + c] b_c.  cn == 1: means [0] mI, [1] mII, [2] mp, [3] mIp -> out [0] a, [1] b.
 __global__ __launch_bounds__(256) void k_gf_coeff(const float *__restrict__ means, size_t plane, long long n, int cn, float eps,
@@ -962,7 +1030,9 @@ int sr_color_correct_u8(sr_ctx *ctx, const uint8_t *d_img, int64_t stride, int h
         const size_t plane = (size_t)h * w;
         float *buf = nullptr;
         {
-            hipError_t e = hipMalloc((void **)&buf, (size_t)(2 * cn + nmean + 2 * nab) * plane * sizeof(float));
+            // (the fused second stage of the 3-channel radius-8 case never writes the mean planes of a / b)
+            const int nmab = (cn == 3 && R == GB_R) ? 0 : nab;
+            hipError_t e = hipMalloc((void **)&buf, (size_t)(2 * cn + nmean + nab + nmab) * plane * sizeof(float));
             if (e != hipSuccess)
                 return sr_set_error(e == hipErrorOutOfMemory ? SR_ERR_OOM : SR_ERR_HIP, "sr_color_correct_u8: %s", hipGetErrorString(e));
         }
@@ -998,9 +1068,15 @@ int sr_color_correct_u8(sr_ctx *ctx, const uint8_t *d_img, int64_t stride, int h
             }
             hipLaunchKernelGGL(k_gf_coeff, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, ctx->stream, (const float *)means, plane,
                                (long long)plane, cn, eps, ab);
-            for (int k = 0; k < nab; ++k) box(ab + (size_t)k * plane, nullptr, mab + (size_t)k * plane);
-            hipLaunchKernelGGL(k_gf_out, g4, b4, 0, ctx->stream, (const float *)planes, (const float *)mab, plane, h, w, cn, d_out,
-                               (long long)out_stride);
+            if (cn == 3 && R == GB_R) {                            // the reference's setting: second stage + output per channel
+                for (int c = 0; c < 3; ++c)
+                    hipLaunchKernelGGL(k_gf_box17_out, gt17, dim3(256), 0, ctx->stream, (const float *)ab, (const float *)planes, plane,
+                                       3 * c, 9 + c, h, w, scale, c, d_out, (long long)out_stride);
+            } else {
+                for (int k = 0; k < nab; ++k) box(ab + (size_t)k * plane, nullptr, mab + (size_t)k * plane);
+                hipLaunchKernelGGL(k_gf_out, g4, b4, 0, ctx->stream, (const float *)planes, (const float *)mab, plane, h, w, cn, d_out,
+                                   (long long)out_stride);
+            }
         }
         int rc2 = check_launch("guided_ximgproc");
         hipError_t es2 = stream_sync(ctx);
