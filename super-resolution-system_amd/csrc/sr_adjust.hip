@@ -793,14 +793,180 @@ __global__ __launch_bounds__(256) void k_gf_box17(const float *__restrict__ A, c
     }
 }
 
+// First stage of the colour guided filter in ONE launch, for an integer-valued guide table (histogram matching, 'none'): the
+// 21 box means (m_i, m_ij, mp_c, mIp_ic) are means of integers whose 289-term sums stay below 2^25 -- exact in any order -- so
+// they run as 32-bit sliding sums straight from the u8 image and (float)((double)S * (1 / 289)) is the float cv::boxFilter's
+// ordered fp64 sum rounds to.  A block owns 64 x 16 positions; its (64 + 16) x (16 + 16) window sits in LDS as six bytes per
+// pixel (I_0 I_1 I_2 p_0 p_1 p_2, BORDER_REFLECT).  The maps are taken in five groups of at most five (LDS: 5 column-sum
+// planes): pass V -- item = (column, map): the 32 products of its column, sliding 17-row sums; pass H -- a thread owns four
+// neighbouring positions of one row: sliding 17-column sums.  After the two covariance groups the thread inverts its four
+// 3 x 3 matrices (k_gf_coeff's expressions in k_gf_coeff's order); after each source channel's group it writes a_c0..2, b_c.
+// The 21 mean planes, the 6 float planes and 21 box launches + k_gf_coeff (20 ms of the 30) are gone.
+#define GC_TW 64
+#define GC_TH 16
+#define GC_WW (GC_TW + 16)                 /* window columns */
+#define GC_WH (GC_TH + 16)                 /* window rows */
+#define GC_NG 5                            /* maps per group */
+
+// map m of the 21: which two of the six window bytes multiply (second = -1: the byte itself)
+__device__ __forceinline__ void gc_map_bytes(int m, int &b0, int &b1)
+{
+    // [0..2] I_i   [3..8] I_i I_j (00 01 02 11 12 22)   [9..11] p_c   [12..20] I_i p_c (c * 3 + i)
+    if (m < 3) { b0 = m; b1 = -1; }
+    else if (m < 9) {
+        const int k = m - 3;
+        b0 = k < 3 ? 0 : (k < 5 ? 1 : 2);
+        b1 = k < 3 ? k : (k < 5 ? k - 2 : 2);
+    } else if (m < 12) { b0 = 3 + (m - 9); b1 = -1; }
+    else { const int k = m - 12; b0 = k % 3; b1 = 3 + k / 3; }
+}
+
+#ifndef GC_MINB
+#define GC_MINB 1
+#endif
+__global__ __launch_bounds__(256, GC_MINB) void k_gfx_coeff17(const unsigned char *__restrict__ img, long long stride, int h, int w,
+                                                     const unsigned char *__restrict__ glutb, float eps, double scale,
+                                                     float *__restrict__ ab, size_t plane)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char win[GC_WH * GC_WW * 6];          // 15 KB
+    __shared__ __attribute__((aligned(16))) unsigned V[GC_NG][GC_TH][GC_WW];               // 25 KB: 40 KB in all, four blocks per CU
+    unsigned char *lutb = (unsigned char *)&V[0][0][0];            // the table is only needed while the window is filled
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * GC_TW, y0 = blockIdx.y * GC_TH;
+    for (int i = tid; i < 768; i += 256) lutb[i] = glutb[i];
+    __syncthreads();
+    for (int e = tid; e < GC_WH * GC_WW; e += 256) {
+        const int py = e / GC_WW, px = e - py * GC_WW;
+        const unsigned char *s = img + (size_t)gf_reflect(y0 + py - 8, h) * stride + (size_t)gf_reflect(x0 + px - 8, w) * 3;
+        unsigned char *d = win + e * 6;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const unsigned char v = s[c];
+            d[c] = lutb[c * 256 + v];
+            d[3 + c] = v;
+        }
+    }
+    const int r = tid >> 4, q = tid & 15;                          // pass H / the algebra: row r, columns 4 q .. 4 q + 3
+    float mean[4][9];                                              // m_0..2, then the six second moments (later: the inverse)
+    float inv[4][6];
+    // groups: 0 = maps 0..4, 1 = maps 5..8, 2 + c = maps 9 + c, 12 + 3 c .. 14 + 3 c
+#pragma unroll
+    for (int grp = 0; grp < 5; ++grp) {
+        const int nmap = grp == 0 ? 5 : 4;
+        __syncthreads();                                           // window ready / the previous group's V consumed
+#pragma unroll 1
+        for (int e = tid; e < nmap * GC_WW; e += 256) {
+            const int k = e / GC_WW, col = e - k * GC_WW;
+            const int m = grp == 0 ? k : (grp == 1 ? 5 + k : (k == 0 ? 9 + (grp - 2) : 12 + 3 * (grp - 2) + (k - 1)));
+            int b0, b1;
+            gc_map_bytes(m, b0, b1);
+            const unsigned char *cp = win + col * 6;
+            unsigned pr[GC_WH];
+#pragma unroll
+            for (int i = 0; i < GC_WH; ++i) {
+                const unsigned a = cp[i * GC_WW * 6 + b0];
+                const unsigned b = b1 >= 0 ? (unsigned)cp[i * GC_WW * 6 + b1] : 1u;
+                // opaque product: hipcc 7.2 folds sums of byte products into v_perm_b32 + v_dot4_u32_u8 and gets them wrong
+                asm("v_mul_u32_u24_e32 %0, %1, %2" : "=v"(pr[i]) : "v"(a), "v"(b));
+                if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // eight rows' bytes in flight, not all 32 (registers)
+            }
+            unsigned sacc = 0;
+#pragma unroll
+            for (int i = 0; i < 17; ++i) sacc += pr[i];
+#pragma unroll
+            for (int o = 0; o < GC_TH; ++o) {
+                if (o > 0) sacc += pr[o + 16] - pr[o - 1];
+                V[k][o][col] = sacc;
+            }
+        }
+        __syncthreads();
+        float val[GC_NG][4];
+#pragma unroll
+        for (int k = 0; k < GC_NG; ++k) {
+            if (k < nmap) {
+                const uint4 *vp = (const uint4 *)&V[k][r][4 * q];
+                const uint4 u0 = vp[0], u1 = vp[1], u2 = vp[2], u3 = vp[3], u4 = vp[4];
+                const unsigned t[20] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w, u2.x, u2.y, u2.z, u2.w, u3.x, u3.y, u3.z, u3.w,
+                                        u4.x, u4.y, u4.z, u4.w};
+                unsigned sacc = 0;
+#pragma unroll
+                for (int i = 0; i < 17; ++i) sacc += t[i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j > 0) sacc += t[j + 16] - t[j - 1];
+                    val[k][j] = (float)((double)sacc * scale);
+                    // pinned here: hipcc otherwise sinks the sums to their first use -- below the next group's passes -- and keeps
+                    // the hundred values loaded from V alive meanwhile (225 VGPRs, two waves per SIMD)
+                    asm volatile("" : "+v"(val[k][j]));
+                }
+                __builtin_amdgcn_sched_barrier(0);                 // one map's twenty values at a time (registers)
+            }
+        }
+        if (grp == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int k = 0; k < 5; ++k) mean[j][k] = val[k][j];
+        } else if (grp == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) mean[j][5 + k] = val[k][j];
+                const float m0 = mean[j][0], m1 = mean[j][1], m2 = mean[j][2];
+                const float c00 = (mean[j][3] - m0 * m0) + eps, c01 = mean[j][4] - m0 * m1, c02 = mean[j][5] - m0 * m2;
+                const float c11 = (mean[j][6] - m1 * m1) + eps, c12 = mean[j][7] - m1 * m2, c22 = (mean[j][8] - m2 * m2) + eps;
+                const float A00 = c11 * c22 - c12 * c12, A01 = c02 * c12 - c01 * c22, A02 = c01 * c12 - c02 * c11;
+                const float A11 = c00 * c22 - c02 * c02, A12 = c01 * c02 - c00 * c12, A22 = c00 * c11 - c01 * c01;
+                const float det = (c00 * A00 + c01 * A01) + c02 * A02;
+                inv[j][0] = A00 / det; inv[j][1] = A01 / det; inv[j][2] = A02 / det;
+                inv[j][3] = A11 / det; inv[j][4] = A12 / det; inv[j][5] = A22 / det;
+                __builtin_amdgcn_sched_barrier(0);                 // one matrix at a time (registers)
+            }
+        } else {
+            const int c = grp - 2;
+            float4 o0, o1, o2, ob;
+            float a0v[4], a1v[4], a2v[4], bv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float m0 = mean[j][0], m1 = mean[j][1], m2 = mean[j][2];
+                const float mp = val[0][j];
+                const float v0 = val[1][j] - m0 * mp, v1 = val[2][j] - m1 * mp, v2 = val[3][j] - m2 * mp;
+                const float i00 = inv[j][0], i01 = inv[j][1], i02 = inv[j][2], i11 = inv[j][3], i12 = inv[j][4], i22 = inv[j][5];
+                a0v[j] = (i00 * v0 + i01 * v1) + i02 * v2;
+                a1v[j] = (i01 * v0 + i11 * v1) + i12 * v2;
+                a2v[j] = (i02 * v0 + i12 * v1) + i22 * v2;
+                bv[j] = mp - ((a0v[j] * m0 + a1v[j] * m1) + a2v[j] * m2);
+            }
+            o0.x = a0v[0]; o0.y = a0v[1]; o0.z = a0v[2]; o0.w = a0v[3];
+            o1.x = a1v[0]; o1.y = a1v[1]; o1.z = a1v[2]; o1.w = a1v[3];
+            o2.x = a2v[0]; o2.y = a2v[1]; o2.z = a2v[2]; o2.w = a2v[3];
+            ob.x = bv[0]; ob.y = bv[1]; ob.z = bv[2]; ob.w = bv[3];
+            const int y = y0 + r, x = x0 + 4 * q;
+            if (y < h && x < w) {
+                const size_t o = (size_t)y * w + x;
+                float *p0 = ab + (size_t)(3 * c) * plane + o, *p1 = p0 + plane, *p2 = p1 + plane, *pb = ab + (size_t)(9 + c) * plane + o;
+                if (x + 3 < w && (w & 3) == 0) {
+                    *(float4 *)p0 = o0; *(float4 *)p1 = o1; *(float4 *)p2 = o2; *(float4 *)pb = ob;
+                } else {
+                    for (int j = 0; j < 4 && x + j < w; ++j) { p0[j] = a0v[j]; p1[j] = a1v[j]; p2[j] = a2v[j]; pb[j] = bv[j]; }
+                }
+            }
+        }
+    }
+}
+
 // Second stage of the colour guided filter for one source channel in ONE launch: the 17 x 17 box means of a_0, a_1, a_2 and b
 // (the planes ab[first], ab[first + 1], ab[first + 2], ab[bplane]) formed one after the other with k_gf_box17's passes, the
 // eight means per map of a thread kept in registers, then q = ((mean_a0 * I_0 + mean_a1 * I_1) + mean_a2 * I_2) + mean_b ->
 // clip -> truncate.  Replaces four box launches + a quarter of k_gf_out: the twelve mean planes are never written.
 __global__ __launch_bounds__(256) void k_gf_box17_out(const float *__restrict__ ab, const float *__restrict__ planes, size_t plane,
                                                       int first, int bplane, int h, int w, double scale, int c,
-                                                      unsigned char *__restrict__ out, long long ostride)
+                                                      unsigned char *__restrict__ out, long long ostride,
+                                                      const unsigned char *__restrict__ img, long long stride,
+                                                      const float *__restrict__ glut)
 {
+    // the guide values I_m come from the float planes, or (planes == nullptr: the fused first stage never made them) from the
+    // image through the guide table -- the same floats
     __shared__ __attribute__((aligned(16))) float pt[GB_PH * GB_PW];
     __shared__ __attribute__((aligned(16))) double hs[GB_PH * GB_TW];
     const int tid = threadIdx.x, anchor = GB_R / 2;
@@ -844,7 +1010,9 @@ __global__ __launch_bounds__(256) void k_gf_box17_out(const float *__restrict__ 
             for (int j = 0; j < 8; ++j) {
                 const float mean = (float)(o[j] * scale);
                 const int y = min(y0 + 8 * g + j, h - 1);
-                const float gi = m < 3 ? planes[(size_t)m * plane + (size_t)y * w + min(x, w - 1)] : 0.0f;
+                const int xc = min(x, w - 1);
+                const float gi = m >= 3 ? 0.0f : planes ? planes[(size_t)m * plane + (size_t)y * w + xc]
+                                                        : glut[m * 256 + img[(size_t)y * stride + (size_t)xc * 3 + m]];
                 acc[j] = m == 0 ? mean * gi : (m < 3 ? acc[j] + mean * gi : acc[j] + mean);
             }
         }
@@ -1028,6 +1196,42 @@ int sr_color_correct_u8(sr_ctx *ctx, const uint8_t *d_img, int64_t stride, int h
         if (cn != 1 && cn != 3) return sr_set_error(SR_ERR_INVALID_ARG, "sr_color_correct_u8: the ximgproc guided filter takes 1 or 3 channels");
         const int R = 2 * radius + 1, nmean = cn == 3 ? 21 : 4, nab = cn == 3 ? 12 : 2;
         const size_t plane = (size_t)h * w;
+        if (cn == 3 && R == GB_R && !env_flag_off("SR_GF_FUSED")) {
+            // the reference's setting with an integer-valued guide table: first stage in one launch (exact 32-bit sliding sums),
+            // second stage + output in one launch per channel; the only temporaries are the twelve a / b planes
+            unsigned char tabb[3 * 256];
+            bool whole = true;
+            for (int i = 0; i < 3 * 256 && whole; ++i) {
+                const float v = h_glut[i];
+                whole = v >= 0.0f && v <= 255.0f && v == (float)(int)v;
+                tabb[i] = (unsigned char)(whole ? (int)v : 0);
+            }
+            if (whole) {
+                unsigned char *d_glutb = (unsigned char *)scr + tab_bytes;
+                HIPCHK(upload_small(ctx, d_glutb, tabb, sizeof(tabb)));
+                float *ab2 = nullptr;
+                hipError_t e = hipMalloc((void **)&ab2, (size_t)12 * plane * sizeof(float));
+                if (e != hipSuccess)
+                    return sr_set_error(e == hipErrorOutOfMemory ? SR_ERR_OOM : SR_ERR_HIP, "sr_color_correct_u8: %s", hipGetErrorString(e));
+                const double sc = 1.0 / ((double)R * (double)R);
+                {
+                    ProfScope ps(ctx, "guided_ximgproc");
+                    hipLaunchKernelGGL(k_gfx_coeff17, dim3((w + GC_TW - 1) / GC_TW, (h + GC_TH - 1) / GC_TH), dim3(256), 0, ctx->stream,
+                                       d_img, (long long)stride, h, w, (const unsigned char *)d_glutb, eps, sc, ab2, plane);
+                    const dim3 g17((w + GB_TW - 1) / GB_TW, (h + GB_TH - 1) / GB_TH);
+                    for (int c = 0; c < 3; ++c)
+                        hipLaunchKernelGGL(k_gf_box17_out, g17, dim3(256), 0, ctx->stream, (const float *)ab2, (const float *)nullptr, plane,
+                                           3 * c, 9 + c, h, w, sc, c, d_out, (long long)out_stride, d_img, (long long)stride,
+                                           (const float *)d_glut);
+                }
+                int rcf = check_launch("guided_ximgproc");
+                hipError_t esf = stream_sync(ctx);
+                (void)hipFree(ab2);
+                if (rcf) return rcf;
+                if (esf != hipSuccess) return sr_set_error(SR_ERR_HIP, "sr_color_correct_u8: %s", hipGetErrorString(esf));
+                return SR_OK;
+            }
+        }
         float *buf = nullptr;
         {
             // (the fused second stage of the 3-channel radius-8 case never writes the mean planes of a / b)
@@ -1071,7 +1275,8 @@ int sr_color_correct_u8(sr_ctx *ctx, const uint8_t *d_img, int64_t stride, int h
             if (cn == 3 && R == GB_R) {                            // the reference's setting: second stage + output per channel
                 for (int c = 0; c < 3; ++c)
                     hipLaunchKernelGGL(k_gf_box17_out, gt17, dim3(256), 0, ctx->stream, (const float *)ab, (const float *)planes, plane,
-                                       3 * c, 9 + c, h, w, scale, c, d_out, (long long)out_stride);
+                                       3 * c, 9 + c, h, w, scale, c, d_out, (long long)out_stride, (const unsigned char *)nullptr, 0ll,
+                                       (const float *)nullptr);
             } else {
                 for (int k = 0; k < nab; ++k) box(ab + (size_t)k * plane, nullptr, mab + (size_t)k * plane);
                 hipLaunchKernelGGL(k_gf_out, g4, b4, 0, ctx->stream, (const float *)planes, (const float *)mab, plane, h, w, cn, d_out,

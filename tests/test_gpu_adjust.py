@@ -114,7 +114,7 @@ def test_mixed_channel_tiles_raise(rng):
 
 
 @pytest.mark.parametrize("method", ["histogram", "mean_std"])
-def test_color_correction_ximgproc_branch(rng, method):
+def test_color_correction_ximgproc_branch(rng, method, monkeypatch):
     """The try-branch of _guided_filter (blending_module.py:1108-1111: cv2.ximgproc.guidedFilter, what runs with
     opencv-contrib installed), selected with guided_filter='ximgproc': (2 r + 1)^2 window, colour guide with the per-pixel
     3 x 3 covariance inverse.  Bit-exact vs oracle_np.guided_filter_ximgproc, which restates it -- PARITY UNPINNED (no cv2
@@ -135,7 +135,15 @@ def test_color_correction_ximgproc_branch(rng, method):
     assert np.array_equal(bx.color_correction(tiny, tiny[::-1].copy(), method=method),
                           onp.color_correction(tiny, tiny[::-1].copy(), method=method, guided="ximgproc"))
     wide = _scene(rng, 130, 256)                                 # width a multiple of 4: the 17 x 17 box kernel's interior blocks
-    assert np.array_equal(bx.color_correction(wide, ref, method=method),
-                          onp.color_correction(wide, ref, method=method, guided="ximgproc"))
+    want_wide = onp.color_correction(wide, ref, method=method, guided="ximgproc")
+    assert np.array_equal(bx.color_correction(wide, ref, method=method), want_wide)
+    # histogram matching has an integer guide table: its first stage is ONE kernel of exact sliding sums (k_gfx_coeff17);
+    # SR_GF_FUSED=0 takes the box-mean launches instead -- the same bytes either way
+    monkeypatch.setenv("SR_GF_FUSED", "0")
+    assert np.array_equal(bx.color_correction(wide, ref, method=method), want_wide)
+    assert np.array_equal(bx.color_correction(img, ref, method=method), want)
+    monkeypatch.delenv("SR_GF_FUSED")
+    noise = rng.integers(0, 256, (97, 203, 3), dtype=np.uint8)
+    assert np.array_equal(bx.color_correction(noise, ref, method=method), onp.color_correction(noise, ref, method=method, guided="ximgproc"))
     with pytest.raises(ValueError):
         BlendingModule(guided_filter="bilateral")
