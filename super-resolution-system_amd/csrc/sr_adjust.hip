@@ -796,8 +796,8 @@ __global__ __launch_bounds__(256) void k_gf_box17(const float *__restrict__ A, c
 // First stage of the colour guided filter in ONE launch, for an integer-valued guide table (histogram matching, 'none'): the
 // 21 box means (m_i, m_ij, mp_c, mIp_ic) are means of integers whose 289-term sums stay below 2^25 -- exact in any order -- so
 // they run as 32-bit sliding sums straight from the u8 image and (float)((double)S * (1 / 289)) is the float cv::boxFilter's
-// ordered fp64 sum rounds to.  A block owns 64 x 16 positions; its (64 + 16) x (16 + 16) window sits in LDS as six bytes per
-// pixel (I_0 I_1 I_2 p_0 p_1 p_2, BORDER_REFLECT).  The maps are taken in five groups of at most five (LDS: 5 column-sum
+// ordered fp64 sum rounds to.  A block owns 64 x 16 positions; its (64 + 16) x (16 + 16) window sits in LDS as six byte
+// planes (I_0 I_1 I_2 p_0 p_1 p_2, BORDER_REFLECT).  The maps are taken in five groups of at most five (LDS: 5 column-sum
 // planes): pass V -- item = (column, map): the 32 products of its column, sliding 17-row sums; pass H -- a thread owns four
 // neighbouring positions of one row: sliding 17-column sums.  After the two covariance groups the thread inverts its four
 // 3 x 3 matrices (k_gf_coeff's expressions in k_gf_coeff's order); after each source channel's group it writes a_c0..2, b_c.
@@ -838,12 +838,11 @@ __global__ __launch_bounds__(256, GC_MINB) void k_gfx_coeff17(const unsigned cha
     for (int e = tid; e < GC_WH * GC_WW; e += 256) {
         const int py = e / GC_WW, px = e - py * GC_WW;
         const unsigned char *s = img + (size_t)gf_reflect(y0 + py - 8, h) * stride + (size_t)gf_reflect(x0 + px - 8, w) * 3;
-        unsigned char *d = win + e * 6;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const unsigned char v = s[c];
-            d[c] = lutb[c * 256 + v];
-            d[3 + c] = v;
+        for (int c = 0; c < 3; ++c) {                              // six byte PLANES: the lanes of pass V read consecutive bytes
+            const unsigned char v = s[c];                          // (interleaved pixels: 1.0 G bank-conflict cycles per image)
+            win[c * (GC_WH * GC_WW) + e] = lutb[c * 256 + v];
+            win[(3 + c) * (GC_WH * GC_WW) + e] = v;
         }
     }
     const int r = tid >> 4, q = tid & 15;                          // pass H / the algebra: row r, columns 4 q .. 4 q + 3
@@ -860,12 +859,12 @@ __global__ __launch_bounds__(256, GC_MINB) void k_gfx_coeff17(const unsigned cha
             const int m = grp == 0 ? k : (grp == 1 ? 5 + k : (k == 0 ? 9 + (grp - 2) : 12 + 3 * (grp - 2) + (k - 1)));
             int b0, b1;
             gc_map_bytes(m, b0, b1);
-            const unsigned char *cp = win + col * 6;
+            const unsigned char *cp0 = win + b0 * (GC_WH * GC_WW) + col, *cp1 = win + max(b1, 0) * (GC_WH * GC_WW) + col;
             unsigned pr[GC_WH];
 #pragma unroll
             for (int i = 0; i < GC_WH; ++i) {
-                const unsigned a = cp[i * GC_WW * 6 + b0];
-                const unsigned b = b1 >= 0 ? (unsigned)cp[i * GC_WW * 6 + b1] : 1u;
+                const unsigned a = cp0[i * GC_WW];
+                const unsigned b = b1 >= 0 ? (unsigned)cp1[i * GC_WW] : 1u;
                 // opaque product: hipcc 7.2 folds sums of byte products into v_perm_b32 + v_dot4_u32_u8 and gets them wrong
                 asm("v_mul_u32_u24_e32 %0, %1, %2" : "=v"(pr[i]) : "v"(a), "v"(b));
                 if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // eight rows' bytes in flight, not all 32 (registers)
