@@ -114,3 +114,51 @@ def test_histogram_lut_vs_cdf_matching():
     want = np.clip(np.searchsorted(cr, cs, side="left"), 0, 255)
     occupied = src > 0
     assert np.abs(lut[occupied].astype(int) - want[occupied]).max() <= 1
+
+
+def test_guided_filters_vs_scipy_uniform_filter():
+    """Both branches of BlendingModule._guided_filter (blending_module.py:1092-1146) rebuilt from scipy.ndimage.uniform_filter in
+    float64 -- He et al.'s formulas, nothing shared with the oracle's box sums: `_simple_guided_filter`'s cv2.blur((8, 8)) is an
+    8-wide window anchored at 4 with BORDER_REFLECT_101 (scipy: size 8, mode 'mirror' -- its even window also spans
+    i - 4 .. i + 3), cv2.ximgproc.guidedFilter's a (2 r + 1)-wide window with BORDER_REFLECT (scipy 'reflect'), gray and colour
+    guide.  Fixes window, anchor, border and the algebra; float32 vs float64 rounding is the only difference left."""
+    from scipy.ndimage import uniform_filter
+    rng = np.random.default_rng(11)
+    yy, xx = np.mgrid[0:61, 0:83]
+    src = np.clip(120 + 60 * np.sin(xx / 9.0) + 40 * np.cos(yy / 7.0) + rng.integers(-20, 21, (61, 83)), 0, 255).astype(np.float32)
+    guide = np.clip(src * 0.8 + 30 + rng.integers(-6, 7, src.shape), 0, 255).astype(np.float32)
+    eps = 0.01
+
+    def gf(g, p, box):
+        g, p = g.astype(np.float64), p.astype(np.float64)
+        mg, mp = box(g), box(p)
+        a = (box(g * p) - mg * mp) / (box(g * g) - mg * mg + eps)
+        b = mp - a * mg
+        return box(a) * g + box(b)
+
+    want = gf(guide, src, lambda x: uniform_filter(x, size=8, mode="mirror"))
+    got = onp.simple_guided_filter(guide, src, 8, eps)
+    assert np.max(np.abs(got - want)) < 2e-3 and np.mean(np.abs(got - want)) < 2e-4      # measured 1.4e-4 / 1.3e-5: float32 rounding
+    want = gf(guide, src, lambda x: uniform_filter(x, size=17, mode="reflect"))
+    got = onp.guided_filter_ximgproc(guide, src, 8, eps)
+    assert np.max(np.abs(got - want)) < 2e-3 and np.mean(np.abs(got - want)) < 2e-4      # measured 5e-5 / 7e-6
+    # colour guide: per pixel (Sigma + eps I)^-1 cov(I, p), solved with numpy.linalg in float64
+    I = np.stack([guide, np.clip(guide[::-1] * 0.5 + 60, 0, 255), np.clip(255 - guide * 0.7, 0, 255)], axis=-1).astype(np.float32)
+    P = np.stack([src, src[:, ::-1].copy(), np.clip(src * 0.5 + 40, 0, 255)], axis=-1).astype(np.float32)
+    box = lambda x: uniform_filter(x, size=17, mode="reflect")
+    I64, P64 = I.astype(np.float64), P.astype(np.float64)
+    m = np.stack([box(I64[..., i]) for i in range(3)], axis=-1)
+    S = np.empty(I.shape[:2] + (3, 3))
+    for i in range(3):
+        for j in range(3):
+            S[..., i, j] = box(I64[..., i] * I64[..., j]) - m[..., i] * m[..., j] + (eps if i == j else 0.0)
+    want3 = np.empty_like(P64)
+    for c in range(3):
+        mp = box(P64[..., c])
+        cov = np.stack([box(I64[..., i] * P64[..., c]) - m[..., i] * mp for i in range(3)], axis=-1)
+        a = np.linalg.solve(S, cov[..., None])[..., 0]
+        b = mp - np.sum(a * m, axis=-1)
+        want3[..., c] = sum(box(a[..., i]) * I64[..., i] for i in range(3)) + box(b)
+    got3 = onp.guided_filter_ximgproc(I, P, 8, eps)
+    d3 = np.abs(got3 - want3)                                    # measured 0.025 / 0.003 grey levels: the float32 cofactor inverse of
+    assert d3.max() < 0.1 and d3.mean() < 6e-3                   # a covariance of three strongly correlated guide channels
