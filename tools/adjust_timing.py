@@ -29,7 +29,8 @@ tiles = torch.randint(0, 256, (len(geo.rects), th, tw * cn), dtype=torch.uint8, 
 def run():
     ctx.histogram_u8(img.data_ptr(), W * cn, H, W, cn)
     ctx.color_correct_u8(img.data_ptr(), W * cn, H, W, cn, lut, False, 8, 1e-3, out.data_ptr(), W * cn)
-    ctx.color_correct_u8(img.data_ptr(), W * cn, H, W, cn, lut, True, 8, 1e-3, out.data_ptr(), W * cn)
+    ctx.color_correct_u8(img.data_ptr(), W * cn, H, W, cn, lut, 1, 8, 1e-3, out.data_ptr(), W * cn)      # _simple_guided_filter
+    ctx.color_correct_u8(img.data_ptr(), W * cn, H, W, cn, lut, 2, 8, 1e-3, out.data_ptr(), W * cn)      # the ximgproc branch
     ctx.gray_std_u8(tiles.data_ptr(), len(geo.rects), th * tw * cn, tw * cn, th, tw)
 
 
