@@ -8,8 +8,15 @@
 //                         mean_a * g + mean_b -> clip -> truncate).  Box sums are accumulated in fp64 like cv::boxFilter
 //                         does for CV_32F data (sum type CV_64F) in a fixed order: each window row left to right, then the
 //                         row sums top to bottom; mean = (float)(sum * (1.0 / (r * r))).  Separable through LDS: a block
-//                         owns 64 x 16 output pixels of one channel at a time.
-// Everything is HBM-bound byte / fp32 work (3 B in, 24 B of a / b out and back in, 3 B out per pixel); no MFMA.
+//                         owns 64 x 16 output pixels of one channel at a time.  Since round 3 the reference's setting (radius 8,
+//                         integer-valued guide table) is ONE kernel, k_cc_fused8: exact 32-bit sliding sums for the first
+//                         stage, a and b kept in LDS (9.9 -> 3.4 ms at 200 MP); the passes above remain for float tables
+//                         and other radii.
+//   cv2.ximgproc.guidedFilter (the branch a requirements-complete install takes; parity unpinned): k_gfx_coeff17 (all 21 first-
+//                         stage means + the 3 x 3 inverse in one kernel, integer tables) and k_gf_box17_out (second stage +
+//                         output per channel); k_gf_box / k_gf_box17 / k_gf_coeff / k_gf_out for float tables, gray images
+//                         and other radii.
+// Byte / fp32 / ordered-fp64 stencil work, bound by VALU issue and latency rather than by HBM once a / b stay on chip; no MFMA.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
