@@ -1184,6 +1184,8 @@ int sr_color_correct_u8(sr_ctx *ctx, const uint8_t *d_img, int64_t stride, int h
     if (local_filter && (radius < 1 || radius > 16)) return sr_set_error(SR_ERR_INVALID_ARG, "sr_color_correct_u8: radius must be 1..16");
     const size_t npx = (size_t)h * w * cn;
     const size_t tab_bytes = 4 * 256 * sizeof(float);
+    // the fused kernels read a block's input halo while other blocks store their output: never in place
+    const bool in_place = !(d_out + (size_t)h * out_stride <= d_img || d_img + (size_t)h * stride <= d_out);
     void *scr = nullptr;
     int rc = ctx_scratch(ctx, tab_bytes + 1024 + 256, &scr);
     if (rc) return rc;
@@ -1202,7 +1204,7 @@ int sr_color_correct_u8(sr_ctx *ctx, const uint8_t *d_img, int64_t stride, int h
         if (cn != 1 && cn != 3) return sr_set_error(SR_ERR_INVALID_ARG, "sr_color_correct_u8: the ximgproc guided filter takes 1 or 3 channels");
         const int R = 2 * radius + 1, nmean = cn == 3 ? 21 : 4, nab = cn == 3 ? 12 : 2;
         const size_t plane = (size_t)h * w;
-        if (cn == 3 && R == GB_R && !env_flag_off("SR_GF_FUSED")) {
+        if (cn == 3 && R == GB_R && !in_place && !env_flag_off("SR_GF_FUSED")) {
             // the reference's setting with an integer-valued guide table: first stage in one launch (exact 32-bit sliding sums),
             // second stage + output in one launch per channel; the only temporaries are the twelve a / b planes
             unsigned char tabb[3 * 256];
@@ -1296,7 +1298,7 @@ int sr_color_correct_u8(sr_ctx *ctx, const uint8_t *d_img, int64_t stride, int h
         if (es2 != hipSuccess) return sr_set_error(SR_ERR_HIP, "sr_color_correct_u8: %s", hipGetErrorString(es2));
         return SR_OK;
     }
-    if (radius == CC8_R && h >= 16 && w >= 16 && !env_flag_off("SR_CC_FUSED")) {
+    if (radius == CC8_R && h >= 16 && w >= 16 && !in_place && !env_flag_off("SR_CC_FUSED")) {
         // the reference's setting with an integer-valued guide table (histogram matching, method 'none'): one fused kernel
         unsigned char tabb[4 * 256];
         bool whole = true;

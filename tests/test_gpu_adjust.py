@@ -105,6 +105,24 @@ def test_color_correction_fused_guided_filter(rng, shape, monkeypatch):
     assert np.array_equal(bm.color_correction(noise, ref), onp.color_correction(noise, ref))
 
 
+@pytest.mark.parametrize("mode,guided", [(1, "simple"), (2, "ximgproc")])
+def test_color_correct_in_place(ctx, rng, mode, guided):
+    """sr_color_correct_u8 with the output buffer ON the input: the fused kernels read a block's halo while other blocks store,
+    so an in-place call must take the pass-structured kernels (which convert / filter before anything is stored) and still
+    give the oracle's bytes."""
+    img = _scene(rng, 96, 160)
+    lut = np.tile(np.arange(256, dtype=np.float32), (3, 1))
+    lut[1] = np.clip(np.arange(256) * 0.5 + 40, 0, 255).astype(np.int32)          # an integer table that is not the identity
+    d = ctx.upload(img)
+    ctx.color_correct_u8(d.ptr, 160 * 3, 96, 160, 3, lut, mode, 8, 0.01, d.ptr, 160 * 3)
+    got = ctx.download(d.ptr, img.shape, np.uint8)
+    d.free()
+    corrected = np.stack([lut[c][img[..., c]] for c in range(3)], axis=-1).astype(np.float32)
+    f = onp.simple_guided_filter if guided == "simple" else onp.guided_filter_ximgproc
+    want = np.clip(f(corrected, img.astype(np.float32), 8, 0.01), 0, 255).astype(np.uint8)
+    assert np.array_equal(got, want), int((got != want).sum())
+
+
 def test_mixed_channel_tiles_raise(rng):
     from blending_module import BlendingModule, TileInfo
     bm = BlendingModule()
