@@ -391,7 +391,8 @@ SR_API int sr_resize_cubic_window_u8(sr_ctx *ctx, const uint8_t *d_src, int64_t 
  * cv2.blur((radius, radius)) box means -- anchor radius / 2, REFLECT_101 -- and fp32 element-wise algebra); with
  * local_filter == 2 through the cv2.ximgproc.guidedFilter branch of :1108-1111 instead ((2 radius + 1)^2 window,
  * BORDER_REFLECT, colour guide: per-pixel 3 x 3 covariance inverse; 1 or 3 channels; restated, parity unpinned).
- * radius 1..16. */
+ * radius 1..16.  d_out may be d_img (in place).  At the reference's radius 8 with an integer-valued table both branches run as
+ * fused kernels (the a / b coefficient planes of branch 1 never leave the CU); results do not depend on which kernels run. */
 SR_API int sr_histogram_u8(sr_ctx *ctx, const uint8_t *d_img, int64_t stride, int h, int w, int cn, uint64_t *h_hist);
 SR_API int sr_color_correct_u8(sr_ctx *ctx, const uint8_t *d_img, int64_t stride, int h, int w, int cn,
                                const float *h_glut, int local_filter, int radius, float eps, uint8_t *d_out,
