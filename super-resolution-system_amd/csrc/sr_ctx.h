@@ -53,6 +53,10 @@ struct sr_ctx {
     CachedTable cubic_tab;                              // cubic tables of sr_resize_cubic_u8
     void *gray_planes = nullptr;                        // resized gray planes + SSE partials of the resized assessment
     size_t gray_planes_bytes = 0;
+    // side streams of the final gather (its marched zones and the block kernel write disjoint parts of the canvas and
+    // run beside each other) with the events that fork them off the context's stream and join them back
+    hipStream_t side[2] = {nullptr, nullptr};
+    hipEvent_t side_fork = nullptr, side_join[2] = {nullptr, nullptr};
 };
 
 // Enqueue a small host->device table upload whose source stays alive until the next sync.

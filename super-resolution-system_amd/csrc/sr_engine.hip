@@ -23,6 +23,7 @@
 #include <mutex>
 #include <set>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "sr_ctx.h"
@@ -1651,6 +1652,7 @@ template <int DT, int CN>
 __global__ __launch_bounds__(FU_THREADS, FU_WAVES) void k_final_fused(const FinalDesc *__restrict__ descs, const int *__restrict__ cand_off,
                                                         const int *__restrict__ cand_idx, const int4 *__restrict__ edge_blocks,
                                                         const int *__restrict__ edge_cand, int n_edge, int nbx_r,
+                                                        const int *__restrict__ reg_list,
                                                         const float *__restrict__ arena, const float *__restrict__ luts,
                                                         unsigned char *__restrict__ canvas, long long cstride,
                                                         float *__restrict__ canvas_f32, int cw, int row_begin, int row_end)
@@ -1664,7 +1666,10 @@ __global__ __launch_bounds__(FU_THREADS, FU_WAVES) void k_final_fused(const Fina
     // (Measured and rejected: a workgroup marching down several blocks of a column -- one dispatch, halo rows still in
     // the CU's caches -- is slower, 1.37 -> 1.52 ms at 16 blocks: the blocks of a march run strictly one after the other
     // and each is a chain of dependent memory round trips; independent blocks overlap them.)
-    const int blk = (int)blockIdx.x - n_edge;
+    // the regular blocks that are left once the marched zones (sr_march.inc) are taken out: block id and, per cell row of
+    // the block, the mask of the cell columns a march item covers
+    const int *rl = reg_list + 9 * ((int)blockIdx.x - n_edge);
+    const int blk = rl[0];
     const int by = blk / nbx_r, bx = blk - by * nbx_r;
     const int c_begin = cand_off[blk], c_end = cand_off[blk + 1];
     const int tid = threadIdx.x;
@@ -1673,7 +1678,7 @@ __global__ __launch_bounds__(FU_THREADS, FU_WAVES) void k_final_fused(const Fina
     const int nx = min(4, cw - x0), ny = min(2, row_end - y0);
     // a cell with any border visit belongs to the edge blocks (which recompute every visit of it): it stops
     // accumulating at its first border visit and stores nothing
-    bool alive = x0 < cw && y0 < row_end;
+    bool alive = x0 < cw && y0 < row_end && !(((unsigned)rl[1 + (tid >> 5)] >> (tid & 31)) & 1u);
     float acc[2][4][CN], wacc[2][4];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -1717,6 +1722,8 @@ __global__ __launch_bounds__(FU_THREADS, FU_WAVES) void k_final_fused(const Fina
     }
     if (alive) store_pixels<CN>(acc, wacc, canvas, cstride, canvas_f32, cw, x0, y0, nx, ny);   // ragged cells without a visit: zeros
 }
+
+#include "sr_march.inc"
 
 // ---------------------------------------------------------------------------------------------
 // dense HWC pyramid primitives (API utilities for build_gaussian_pyramid & friends)
@@ -2983,6 +2990,13 @@ struct sr_blend_plan {
     int *d_fcand_off = nullptr, *d_fcand_idx = nullptr, *d_fedge_cand = nullptr;
     int4 *d_fedge_blocks = nullptr;
     int n_fedge_blocks = 0;
+    // marched zones (k_final_march): work items per tile count, and the regular blocks of k_final_fused that remain
+    bool march = false;
+    MarchItem *d_march_items[MARCH_NT + 1] = {nullptr};
+    int n_march_items[MARCH_NT + 1] = {0};
+    long long n_march_total = 0;
+    int *d_freg_list = nullptr, *d_freg_all = nullptr;      // without the marched zones / every regular block (float tiles): 9 ints each
+    long long n_freg = 0, n_freg_all = 0;
     std::vector<char> sh_srcs, sh_fdesc;                // host shadows of d_srcs / d_fdesc (upload_if_changed)
     CachedTable subset_tabs[4];                         // compacted {TileDev, TileSrc} tables of recent tile subsets
     int subset_next = 0;
@@ -2993,6 +3007,157 @@ struct sr_blend_plan {
 };
 
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// ---------------------------------------------------------------------------------------------
+// Work lists of the marched gather (k_final_march, sr_march.inc).  A cell column (4 canvas pixels) / cell row (2 canvas
+// rows) is, for one tile, 0 = not touched, 1 = marchable (the cell is an interior visit and neither the level-1 columns /
+// rows the lane produces nor their level-2 taps meet a border rule), 2 = touched otherwise.  Between two consecutive class
+// changes of any tile the classes are constant, so the canvas falls into rectangles with a fixed list of visiting tiles;
+// a rectangle is marched when every tile that touches it is marchable in both directions.  Rectangles lose one cell
+// column per side to the halo lanes and are cut into strips of <= MARCH_CELLS cells and segments of <= MARCH_SEG steps
+// (an even number: an odd last cell row stays with the block kernel).
+// reg_list: the regular blocks that still hold unmarched cells, 9 ints each: block id and, per cell row of the block,
+// the mask of its marched cell columns.
+// ---------------------------------------------------------------------------------------------
+static void plan_march(const sr_blend_plan *P, int nbx_r, int nby_r, std::vector<MarchItem> (&items)[MARCH_NT + 1],
+                       std::vector<int> &reg_list)
+{
+    const int rows = P->row_end - P->row_begin, cw = P->canvas_w, n = P->n;
+    const int ncx = cw / 4, ncy = rows / 2;                    // whole cells only: ragged ends are border visits
+    const int CPB = FU_BH / 2;                                 // cell rows per regular block
+    std::vector<unsigned> cover((size_t)nbx_r * nby_r * CPB, 0u);          // [block row][cell row][block column]: cell column bits
+    // the marched kernels address the arena and a tile's pixels with 32-bit byte offsets (buffer instructions)
+    bool fits32 = P->arena_floats * sizeof(float) < 0xFFFF0000ull && (unsigned long long)cw * P->cn * 4ull * (2 * MARCH_SEG + 2) < 0xFFFF0000ull;
+    for (int t = 0; t < n && fits32; ++t) fits32 = (unsigned long long)P->tiles[t].h * P->tiles[t].w * P->cn * 4ull < 0x7FFF0000ull;
+    const bool on = P->march && fits32 && n <= 128 && ncx >= 3 && ncy >= 2;
+    if (on) {
+        auto xclass = [&](const TileDev &T, int x0) -> unsigned char {
+            const long long lx0 = (long long)x0 - T.x;
+            if (lx0 + 4 <= 0 || lx0 >= T.w) return 0;
+            if (T.nl < 3 || lx0 < 0 || lx0 + 3 >= T.w) return 2;
+            const long long c0 = (lx0 - 1) >> 1, n0 = c0 >> 1;
+            if (c0 < 0 || c0 + 3 > T.W[1] - 1 || n0 + 2 > T.W[2] - 1) return 2;
+            return 1;
+        };
+        auto yclass = [&](const TileDev &T, int y0) -> unsigned char {
+            const long long ly0 = (long long)y0 - T.y;
+            if (ly0 + 2 <= 0 || ly0 >= T.h) return 0;
+            if (T.nl < 3 || ly0 < 0 || ly0 + 1 >= T.h) return 2;
+            const long long r0 = (ly0 - 1) >> 1;
+            if (r0 < 1 || r0 + 2 > T.H[1] - 1 || ((r0 + 1) >> 1) + 2 > T.H[2] - 1) return 2;
+            return 1;
+        };
+        std::vector<std::vector<unsigned char>> xc(n, std::vector<unsigned char>(ncx)), yc(n, std::vector<unsigned char>(ncy));
+        std::vector<int> xb{0, ncx}, yb{0, ncy};
+        for (int t = 0; t < n; ++t) {
+            const TileDev &T = P->tiles[t];
+            for (int c = 0; c < ncx; ++c) {
+                xc[t][c] = xclass(T, 4 * c);
+                if (c && xc[t][c] != xc[t][c - 1]) xb.push_back(c);
+            }
+            for (int c = 0; c < ncy; ++c) {
+                yc[t][c] = yclass(T, P->row_begin + 2 * c);
+                if (c && yc[t][c] != yc[t][c - 1]) yb.push_back(c);
+            }
+        }
+        std::sort(xb.begin(), xb.end());
+        xb.erase(std::unique(xb.begin(), xb.end()), xb.end());
+        std::sort(yb.begin(), yb.end());
+        yb.erase(std::unique(yb.begin(), yb.end()), yb.end());
+        struct Strip { int ca, cb, ya, ye, nt, tile[4]; };
+        std::vector<Strip> strips;
+        std::vector<int> vis, run_vis;
+        for (size_t iy = 0; iy + 1 < yb.size(); ++iy) {
+            const int ya = yb[iy], ye = ya + (yb[iy + 1] - ya) / 2 * 2;      // an even number of steps (the loop is unrolled by two)
+            if (ye - ya < 2) continue;
+            // runs of consecutive x intervals with the same (valid) tile list
+            int run_a = -1, run_b = -1;
+            auto flush = [&]() {
+                if (run_a < 0) return;
+                const int ua = run_a + 1, ub = run_b - 1;          // one cell column per side goes to the halo lanes
+                const int nu = ub - ua, nt = (int)run_vis.size();
+                if (nu >= 1) {
+                    const int ns = (nu + MARCH_CELLS - 1) / MARCH_CELLS;
+                    for (int si = 0; si < ns; ++si) {
+                        const int ca = ua + (int)((long long)nu * si / ns), cb = ua + (int)((long long)nu * (si + 1) / ns);
+                        Strip st;
+                        st.ca = ca; st.cb = cb; st.ya = ya; st.ye = ye; st.nt = nt;
+                        for (int k = 0; k < 4; ++k) st.tile[k] = k < nt ? run_vis[k] : 0;
+                        strips.push_back(st);
+                    }
+                    for (int cy = ya; cy < ye; ++cy)
+                        for (int c = ua; c < ub; ++c) cover[(size_t)cy * nbx_r + c / 32] |= 1u << (c & 31);
+                }
+                run_a = -1;
+            };
+            for (size_t ix = 0; ix + 1 < xb.size(); ++ix) {
+                vis.clear();
+                bool ok = true;
+                for (int t = 0; t < n && ok; ++t) {
+                    const unsigned char cx = xc[t][xb[ix]], cy = yc[t][yb[iy]];
+                    if (cx == 0 || cy == 0) continue;
+                    if (cx == 1 && cy == 1) vis.push_back(t);
+                    else ok = false;
+                }
+                ok = ok && !vis.empty() && (int)vis.size() <= MARCH_NT;
+                if (ok && run_a >= 0 && vis == run_vis) {
+                    run_b = xb[ix + 1];
+                    continue;
+                }
+                flush();
+                if (ok) {
+                    run_a = xb[ix];
+                    run_b = xb[ix + 1];
+                    run_vis = vis;
+                }
+            }
+            flush();
+        }
+        // Segment length per tile count: as long as MARCH_SEG steps where that still leaves every wave slot of the GPU a few
+        // items (the warm-up of an item costs about two steps), shorter where a list is small -- a short list of long items
+        // is a latency-bound launch of one or two rounds.
+        long long steps_of[MARCH_NT + 1] = {0};
+        for (const Strip &st : strips) steps_of[st.nt] += st.ye - st.ya;
+        for (int nt = 1; nt <= MARCH_NT; ++nt) {
+            if (!steps_of[nt]) continue;
+            const long long want_items = (long long)P->ctx->num_cu * 8 / nt * 6;           // six rounds at two waves per SIMD
+            int seg = (int)std::min<long long>(MARCH_SEG, std::max<long long>(8, steps_of[nt] / want_items));
+            seg = seg / 2 * 2;
+            for (const Strip &st : strips) {
+                if (st.nt != nt) continue;
+                for (int sy = st.ya; sy < st.ye; sy += seg) {
+                    MarchItem it;
+                    memset(&it, 0, sizeof(it));
+                    it.x0 = 4 * (st.ca - 1);
+                    it.y0 = P->row_begin + 2 * sy;
+                    it.ncell = st.cb - st.ca;
+                    it.nstep = std::min(seg, st.ye - sy);
+                    for (int k = 0; k < nt; ++k) it.tile[k] = st.tile[k];
+                    items[nt].push_back(it);
+                }
+            }
+            if (std::getenv("SR_MARCH_STATS"))
+                fprintf(stderr, "[march] %d-tile zones: %lld strip-steps, segments of %d steps, %zu items\n", nt, steps_of[nt], seg, items[nt].size());
+        }
+    }
+    // the regular blocks that still hold unmarched cells: block id + the marched cell columns of each of its CPB cell rows
+    static_assert(FU_BW == 128 && FU_BH == 16, "one mask word per cell row of a regular block, one bit per cell column");
+    for (int by = 0; by < nby_r; ++by)
+        for (int bx = 0; bx < nbx_r; ++bx) {
+            const int cells = std::min(32, (cw - bx * FU_BW + 3) / 4);
+            const unsigned all = cells >= 32 ? 0xFFFFFFFFu : ((1u << cells) - 1u);
+            const int crows = std::min(CPB, (rows - by * FU_BH + 1) / 2);
+            unsigned m[8];
+            bool dead = true;
+            for (int cy = 0; cy < CPB; ++cy) {
+                m[cy] = cy < crows ? cover[(size_t)(by * CPB + cy) * nbx_r + bx] : 0xFFFFFFFFu;
+                if (cy < crows && (m[cy] & all) != all) dead = false;
+            }
+            if (dead) continue;                                     // every cell of the block is marched
+            reg_list.push_back(by * nbx_r + bx);
+            for (int cy = 0; cy < CPB; ++cy) reg_list.push_back((int)m[cy]);
+        }
+}
 
 bool plan_describe(const sr_blend_plan *p, sr_ctx **ctx, int *n, int *cn)
 {
@@ -3088,6 +3253,14 @@ int sr_ctx_destroy(sr_ctx *ctx)
         if (ctx->extract_tab.d) (void)hipFree(ctx->extract_tab.d);
         if (ctx->resize_tab.d) (void)hipFree(ctx->resize_tab.d);
         if (ctx->cubic_tab.d) (void)hipFree(ctx->cubic_tab.d);
+        for (int i = 0; i < 2; ++i) {
+            if (ctx->side[i]) {
+                (void)hipStreamSynchronize(ctx->side[i]);
+                (void)hipStreamDestroy(ctx->side[i]);
+            }
+            if (ctx->side_join[i]) (void)hipEventDestroy(ctx->side_join[i]);
+        }
+        if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;
@@ -3362,6 +3535,10 @@ int sr_blend_plan_destroy(sr_blend_plan *plan)
         if (plan->d_fcand_idx) (void)hipFree(plan->d_fcand_idx);
         if (plan->d_fedge_blocks) (void)hipFree(plan->d_fedge_blocks);
         if (plan->d_fedge_cand) (void)hipFree(plan->d_fedge_cand);
+        if (plan->d_freg_list) (void)hipFree(plan->d_freg_list);
+        if (plan->d_freg_all) (void)hipFree(plan->d_freg_all);
+        for (int k = 0; k <= MARCH_NT; ++k)
+            if (plan->d_march_items[k]) (void)hipFree(plan->d_march_items[k]);
         for (auto &t : plan->subset_tabs)
             if (t.d) (void)hipFree(t.d);
         if (plan->d_cand_idx) (void)hipFree(plan->d_cand_idx);
@@ -3401,6 +3578,8 @@ int sr_blend_plan_create(sr_ctx *ctx, const sr_tile_rect *h_tiles, int n, int cn
     {
         const char *env = std::getenv("SR_FUSED_FINAL");
         P->fused = (cn == 3 || cn == 1) && !(env && env[0] == '0');     // SR_FUSED_FINAL=0: the unfused pair (A/B runs)
+        const char *env2 = std::getenv("SR_MARCH");
+        P->march = P->fused && !(env2 && env2[0] == '0');               // SR_MARCH=0: every zone through k_final_fused (A/B runs)
     }
 
     std::map<std::pair<int, int>, int> cls_of;
@@ -3728,6 +3907,27 @@ int sr_blend_plan_create(sr_ctx *ctx, const sr_tile_rect *h_tiles, int n, int cn
         if ((e = hipMalloc((void **)&P->d_fcand_idx, sizeof(int) * cidx.size())) != hipSuccess) return fail(e, "fused candidate table");
         if ((e = hipMemcpy(P->d_fcand_off, coff.data(), sizeof(int) * coff.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload");
         if ((e = hipMemcpy(P->d_fcand_idx, cidx.data(), sizeof(int) * cidx.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload");
+        // ---- marched zones and what is left for the regular blocks -----------------------------------------------------
+        std::vector<MarchItem> mitems[MARCH_NT + 1];
+        std::vector<int> reg_list;
+        plan_march(P, nbx_r, nby_r, mitems, reg_list);
+        {
+            std::vector<int> all(nblk * 9, 0);
+            for (size_t b = 0; b < nblk; ++b) all[b * 9] = (int)b;
+            P->n_freg_all = (long long)nblk;
+            if ((e = hipMalloc((void **)&P->d_freg_all, sizeof(int) * all.size())) != hipSuccess) return fail(e, "regular block list");
+            if ((e = hipMemcpy(P->d_freg_all, all.data(), sizeof(int) * all.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload");
+        }
+        P->n_freg = (long long)(reg_list.size() / 9);
+        if ((e = hipMalloc((void **)&P->d_freg_list, sizeof(int) * std::max<size_t>(reg_list.size(), 1))) != hipSuccess) return fail(e, "regular block list");
+        if (!reg_list.empty() && (e = hipMemcpy(P->d_freg_list, reg_list.data(), sizeof(int) * reg_list.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload");
+        for (int k = 1; k <= MARCH_NT; ++k) {
+            P->n_march_items[k] = (int)mitems[k].size();
+            P->n_march_total += (long long)mitems[k].size();
+            if (mitems[k].empty()) continue;
+            if ((e = hipMalloc((void **)&P->d_march_items[k], sizeof(MarchItem) * mitems[k].size())) != hipSuccess) return fail(e, "march items");
+            if ((e = hipMemcpy(P->d_march_items[k], mitems[k].data(), sizeof(MarchItem) * mitems[k].size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload");
+        }
     }
     if ((e = hipMemcpyAsync(P->d_tiles, P->tiles.data(), sizeof(TileDev) * n, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e, "upload");
     if ((e = hipMemcpyAsync(P->d_classes, P->classes.data(), sizeof(TileDev) * P->classes.size(), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e, "upload");
@@ -3920,15 +4120,72 @@ static int blend_gather(sr_blend_plan *P, bool lap, int dtype, void *const *h_d_
         if (lap && P->fused) {
             const int nbx_r = std::max((P->canvas_w + FU_BW - 1) / FU_BW, 1), nby_r = std::max((rows + FU_BH - 1) / FU_BH, 1);
             const int n_edge = P->n_fedge_blocks;
-            const long long n_reg = (long long)nbx_r * nby_r;
+            // the marched zones first (long work items), then the edge and regular blocks of what is left; float tiles take
+            // the regular blocks everywhere
+            const bool marched = dtype == SR_U8 && P->n_march_total > 0;
+            // The marched zones and the block kernel write disjoint cells of the canvas: they run beside each other, the
+            // marched kernels on the context's side streams (forked off its stream here, joined below) with SR_GATHER_STREAMS=1; default:
+            // one after the other on the context's stream (per-kernel timing).
+            static const bool side_ok = std::getenv("SR_GATHER_STREAMS") && std::getenv("SR_GATHER_STREAMS")[0] == '1';
+            bool forked = false;
+            hipStream_t ms[3] = {ctx->stream, ctx->stream, ctx->stream};
+            // (per-kernel timing of the parts wants them one after the other; timing the whole gather, or another family, does not)
+            const bool want_parts = ctx->prof && (ctx->prof_only.empty() || ctx->prof_only.rfind("gather_", 0) == 0);
+            if (marched && side_ok && !want_parts) {
+                if (!ctx->side_fork) {
+                    HIPCHK(hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
+                    for (int i = 0; i < 2; ++i) {
+                        HIPCHK(hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking));
+                        HIPCHK(hipEventCreateWithFlags(&ctx->side_join[i], hipEventDisableTiming));
+                    }
+                }
+                HIPCHK(hipEventRecord(ctx->side_fork, ctx->stream));
+                for (int i = 0; i < 2; ++i) HIPCHK(hipStreamWaitEvent(ctx->side[i], ctx->side_fork, 0));
+                ms[1] = ctx->side[0];
+                ms[2] = ctx->side[1];
+                forked = true;
+            }
+            const unsigned arena_bytes = (unsigned)std::min<size_t>(P->arena_floats * sizeof(float), 0xFFFFFFFFu);
+            if (dtype == SR_U8 && P->n_march_items[1] > 0) {
+                ProfScope ps2(ctx, "gather_march1");
+                if (P->cn == 3)
+                    hipLaunchKernelGGL((k_final_march1<3>), dim3((unsigned)P->n_march_items[1]), dim3(64), 0, ms[1], P->d_march_items[1],
+                                       P->d_fdesc, P->d_arena, arena_bytes, P->d_luts, d_canvas, (long long)canvas_stride, d_canvas_f32, P->canvas_w);
+                else
+                    hipLaunchKernelGGL((k_final_march1<1>), dim3((unsigned)P->n_march_items[1]), dim3(64), 0, ms[1], P->d_march_items[1],
+                                       P->d_fdesc, P->d_arena, arena_bytes, P->d_luts, d_canvas, (long long)canvas_stride, d_canvas_f32, P->canvas_w);
+            }
+#define LAUNCH_MARCHN(CNV, NTV)                                                                                          \
+    hipLaunchKernelGGL((k_final_marchn<CNV, NTV>), dim3((unsigned)P->n_march_items[NTV]), dim3(64 * NTV), 0, ms[2],           \
+                       P->d_march_items[NTV], P->d_fdesc, P->d_arena, arena_bytes, P->d_luts, d_canvas,                      \
+                       (long long)canvas_stride, d_canvas_f32, P->canvas_w)
+            static_assert(MARCH_NT == 4, "the tile counts launched here");
+            for (int nt = 2; nt <= MARCH_NT && dtype == SR_U8; ++nt) {
+                if (P->n_march_items[nt] <= 0) continue;
+                ProfScope ps2(ctx, nt == 2 ? "gather_march2" : (nt == 3 ? "gather_march3" : "gather_march4"));
+                if (P->cn == 3) { if (nt == 2) LAUNCH_MARCHN(3, 2); else if (nt == 3) LAUNCH_MARCHN(3, 3); else LAUNCH_MARCHN(3, 4); }
+                else            { if (nt == 2) LAUNCH_MARCHN(1, 2); else if (nt == 3) LAUNCH_MARCHN(1, 3); else LAUNCH_MARCHN(1, 4); }
+            }
+#undef LAUNCH_MARCHN
+            if (forked) {
+                for (int i = 0; i < 2; ++i) HIPCHK(hipEventRecord(ctx->side_join[i], ctx->side[i]));
+            }
+            const long long n_reg = marched ? P->n_freg : P->n_freg_all;
+            const int *reg_list = marched ? P->d_freg_list : P->d_freg_all;
+            ProfScope ps3(ctx, "gather_rest");
             dim3 grid((unsigned)std::max<long long>(n_edge + n_reg, 1)), blk1(FU_THREADS);
 #define LAUNCH_FUSED(DT, CNV)                                                                                          \
     hipLaunchKernelGGL((k_final_fused<DT, CNV>), grid, blk1, 0, ctx->stream, P->d_fdesc, P->d_fcand_off, P->d_fcand_idx,  \
-                       P->d_fedge_blocks, P->d_fedge_cand, n_edge, nbx_r, P->d_arena, P->d_luts, d_canvas,   \
+                       P->d_fedge_blocks, P->d_fedge_cand, n_edge, nbx_r, reg_list, P->d_arena, P->d_luts, d_canvas,   \
                        (long long)canvas_stride, d_canvas_f32, P->canvas_w, P->row_begin, P->row_end)
-            if (P->cn == 3) { if (dtype == SR_U8) LAUNCH_FUSED(SRC_U8, 3); else LAUNCH_FUSED(SRC_F32, 3); }
-            else            { if (dtype == SR_U8) LAUNCH_FUSED(SRC_U8, 1); else LAUNCH_FUSED(SRC_F32, 1); }
+            if (n_edge + n_reg > 0) {
+                if (P->cn == 3) { if (dtype == SR_U8) LAUNCH_FUSED(SRC_U8, 3); else LAUNCH_FUSED(SRC_F32, 3); }
+                else            { if (dtype == SR_U8) LAUNCH_FUSED(SRC_U8, 1); else LAUNCH_FUSED(SRC_F32, 1); }
+            }
 #undef LAUNCH_FUSED
+            if (forked) {
+                for (int i = 0; i < 2; ++i) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->side_join[i], 0));
+            }
         } else if (P->cn == 3 || P->cn == 1) {
             const int nbx_r = std::max((P->canvas_w + FIN_BW - 1) / FIN_BW, 1), nby_r = std::max((rows + FIN_BH - 1) / FIN_BH, 1);
             dim3 grid((unsigned)(P->n_edge_blocks + (long long)nbx_r * nby_r));     // edge blocks first, then the regular ones
