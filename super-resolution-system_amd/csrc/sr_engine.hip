@@ -1679,6 +1679,31 @@ __global__ __launch_bounds__(FU_THREADS, FU_WAVES) void k_final_fused(const Fina
     // a cell with any border visit belongs to the edge blocks (which recompute every visit of it): it stops
     // accumulating at its first border visit and stores nothing
     bool alive = x0 < cw && y0 < row_end && !(((unsigned)rl[1 + (tid >> 5)] >> (tid & 31)) & 1u);
+    // the cells that are left span a sub-rectangle of the block (thin bands along the marched zones, mostly): the level-1
+    // window is built for that rectangle only (block-uniform: scalar arithmetic on the mask words)
+    int sbx = bx0, sby = by0, sbw = FU_BW, sbh = FU_BH;
+    {
+        const int ncol = min(32, (cw - bx0 + 3) >> 2), nrow = min(FU_BH / 2, (row_end - by0 + 1) >> 1);
+        const unsigned colmask = ncol >= 32 ? 0xFFFFFFFFu : ((1u << ncol) - 1u);
+        unsigned any = 0u;
+        int cy0 = FU_BH / 2, cy1 = -1;
+#pragma unroll
+        for (int cy = 0; cy < FU_BH / 2; ++cy) {
+            const unsigned a = cy < nrow ? (~(unsigned)rl[1 + cy] & colmask) : 0u;
+            if (a) {
+                any |= a;
+                cy0 = min(cy0, cy);
+                cy1 = cy;
+            }
+        }
+        if (any) {
+            const int cx0 = __builtin_ctz(any), cx1 = 31 - __builtin_clz(any);
+            sbx = bx0 + 4 * cx0;
+            sby = by0 + 2 * cy0;
+            sbw = 4 * (cx1 - cx0 + 1);
+            sbh = 2 * (cy1 - cy0 + 1);
+        }
+    }
     float acc[2][4][CN], wacc[2][4];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -1690,9 +1715,9 @@ __global__ __launch_bounds__(FU_THREADS, FU_WAVES) void k_final_fused(const Fina
         }
     for (int i = c_begin; i < c_end; ++i) {
         const FinalDesc &D = descs[cand_idx[i]];
-        const int lxa = bx0 - D.x, lya = by0 - D.y;
+        const int lxa = sbx - D.x, lya = sby - D.y;
         int R0 = 0, C0 = 0, npr = 0, npc = 0;
-        const bool win = D.nl > 1 && fused_window(D, lxa, lya, FU_BW, FU_BH, R0, C0, npr, npc);    // block-uniform
+        const bool win = D.nl > 1 && fused_window(D, lxa, lya, sbw, sbh, R0, C0, npr, npc);        // block-uniform
         const int lx0 = x0 - D.x, ly0 = y0 - D.y;
         bool visit = alive && !(lx0 + nx <= 0 || ly0 + ny <= 0 || lx0 >= D.w || ly0 >= D.h);
         if (visit && !visit_is_interior<true>(D, lx0, ly0, nx, ny)) visit = alive = false;
