@@ -221,75 +221,10 @@ def _stage(name: str) -> None:
 
 
 def _launch_ranks(n: int, argv, deadline_s: float) -> int:
-    """``python bench.py --gpus N`` without a launcher around it: start the N ranks as CHILD processes (one per GPU,
-    env:// rendezvous on 127.0.0.1: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) before anything in this
-    process has touched torch or HIP.  The children write straight to our stdout / stderr (rank 0 prints the JSON
-    line).  Returns the first non-zero child status (the other ranks are then stopped), else 0; after ``deadline_s``
-    seconds the ranks still running are terminated, every rank's last completed stage is printed to stderr and the status
-    is 124.  Never exec: a process that has initialised the GPU must not be replaced -- and this one never initialises it;
-    the children are always fresh processes."""
-    import socket
-    import subprocess
-    import tempfile
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    stage_dir = tempfile.mkdtemp(prefix="sr_bench_stage_")
-    procs = []
-    for r in range(n):
-        env = dict(os.environ)
-        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
-                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
-                    "SR_BENCH_STAGE_FILE": os.path.join(stage_dir, f"rank{r}")})
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
-        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
-
-    def last_stages():
-        out = []
-        for r in range(n):
-            try:
-                lines = open(os.path.join(stage_dir, f"rank{r}")).read().split("\n")
-                lines = [ln for ln in lines if ln]
-                out.append(lines[-1].split(" ", 1)[1] if lines else "(nothing: not past the interpreter start)")
-            except OSError:
-                out.append("(no stage file)")
-        return out
-
-    rc = 0
-    t_end = time.monotonic() + deadline_s
-    alive = list(procs)
-    while alive:
-        for p in list(alive):
-            try:
-                code = p.wait(timeout=0.2)
-            except subprocess.TimeoutExpired:
-                continue
-            alive.remove(p)
-            if code != 0 and rc == 0:
-                rc = code
-                print(f"bench.py: rank {procs.index(p)} exited with status {code}; stopping the others "
-                      f"(last stages: {last_stages()})", file=sys.stderr)
-                for q in alive:                              # a rank failed: the others would wait on it forever
-                    q.terminate()
-        if alive and time.monotonic() > t_end:
-            stages = last_stages()
-            print(f"bench.py: deadline of {deadline_s:.0f} s passed with {len(alive)} of {n} ranks still running", file=sys.stderr)
-            for r, st in enumerate(stages):
-                state = "running" if procs[r] in alive else f"exited {procs[r].returncode}"
-                print(f"bench.py:   rank {r} [{state}] last completed stage: {st}", file=sys.stderr)
-            for q in alive:
-                q.terminate()
-            for q in alive:
-                try:
-                    q.wait(timeout=10)
-                except subprocess.TimeoutExpired:
-                    q.kill()
-            rc = rc or 124
-            break
-    import shutil
-    shutil.rmtree(stage_dir, ignore_errors=True)
-    return rc
+    """``python bench.py --gpus N`` without a launcher around it: the N ranks as fresh child processes
+    (super-resolution-system_amd/_launch.py: env:// rendezvous on 127.0.0.1, per-rank stage markers, deadline -> 124, never exec)."""
+    import _launch
+    return _launch.launch_ranks(n, os.path.abspath(__file__), argv, deadline_s, who="bench.py")
 
 
 def run_workload(args, workload: str, steps: int, warmup: int, detailed: bool, dist_state) -> dict:
