@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import logging
 import os
+import sys
 from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass, field
 from enum import Enum
@@ -194,6 +195,71 @@ class BlendingModule:
         return self._ctx().fusion_np(images, positions, output_shape, self.num_levels, weight_name,
                                      laplacian=laplacian)
 
+    @staticmethod
+    def _dist_world():
+        """(rank, world) of an initialised torch.distributed process group, else (0, 1).  torch is only looked at when the
+        caller has imported it (a process group cannot exist otherwise)."""
+        torch = sys.modules.get("torch")
+        if torch is None or os.environ.get("SR_SHARD_FUSION", "1") == "0":
+            return 0, 1
+        dist = torch.distributed
+        if not (dist.is_available() and dist.is_initialized()):
+            return 0, 1
+        return dist.get_rank(), dist.get_world_size()
+
+    def _fuse_sharded(self, images, positions, output_shape, weight_name: str, rank: int, world: int) -> np.ndarray:
+        """laplacian_fusion across the ranks of the caller's process group (one process per GPU; the reference's own
+        fan-out is ParallelBlender's thread pool, blending_module.py:1665-1705).  The call is SPMD: every rank holds the tile
+        list, so nothing is exchanged before the blend -- a rank uploads, of every tile, only the rows its canvas strip needs
+        (strip + pyramid halo: the window planner's answer), blends its rows with the kernels of the one-GPU path
+        (bit-identical rows) and the strips are all-gathered: every rank returns the whole canvas."""
+        import torch
+        import torch.distributed as dist
+        H, W = int(output_shape[0]), int(output_shape[1])
+        arrs = [np.ascontiguousarray(im) for im in images]
+        cn = arrs[0].shape[2] if arrs[0].ndim == 3 else 1
+        rects = [(int(p[1]), int(p[0]), a.shape[1], a.shape[0]) for a, p in zip(arrs, positions)]
+        bounds = _native.strip_bounds(rects, self.num_levels, H, W, world)
+        a, b = bounds[rank], bounds[rank + 1]
+        if self.device == 0 and "LOCAL_RANK" in os.environ and torch.cuda.device_count() > 1:
+            self.device = int(os.environ["LOCAL_RANK"]) % torch.cuda.device_count()
+        ctx = self._ctx()
+        strip = np.zeros((b - a, W * cn), dtype=np.uint8)
+        if b > a:
+            plan = _native.BlendPlan(ctx, rects, cn, H, W, self.num_levels, weight_name, a, b)
+            bufs, ptrs, strides = [], [], []
+            out = None
+            try:
+                for t, im in enumerate(arrs):
+                    r0, r1 = plan.tile_rows(t)
+                    stride = im.shape[1] * cn
+                    strides.append(stride)
+                    if r0 >= r1:
+                        ptrs.append(0)
+                        continue
+                    buf = ctx.upload(im[r0:r1])
+                    bufs.append(buf)
+                    ptrs.append(buf.ptr - r0 * stride)               # virtual row 0: only rows r0 .. r1 are touched
+                out = ctx.alloc((b - a) * W * cn)
+                plan.blend(ptrs, strides, out.ptr - a * W * cn, W * cn)          # writes canvas rows a .. b only
+                strip = ctx.download(out.ptr, (b - a, W * cn), np.uint8)
+            finally:
+                ctx.sync()
+                plan.close()
+                for buf in bufs + ([out] if out is not None else []):
+                    buf.free()
+        # all-gather of the strips (rows differ per rank: padded to the tallest)
+        tall = max(bounds[r + 1] - bounds[r] for r in range(world))
+        on_gpu = dist.get_backend() == "nccl"
+        mine = torch.zeros((tall, W * cn), dtype=torch.uint8)
+        mine[: b - a] = torch.from_numpy(strip)
+        if on_gpu:
+            mine = mine.cuda(self.device)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        canvas = np.concatenate([parts[r][: bounds[r + 1] - bounds[r]].cpu().numpy() for r in range(world)], axis=0)
+        return canvas.reshape((H, W) if cn == 1 else (H, W, cn))
+
     def fuse_device(self, d_tiles: Sequence[int], strides: Sequence[int], rects_xywh, output_shape: Tuple[int, int],
                     cn: int = 3, weight_type: Union[WeightType, str] = WeightType.COSINE, laplacian: bool = True):
         """laplacian_fusion / weighted_average_fusion on u8 tiles that already live in HBM (device addresses, row
@@ -221,6 +287,10 @@ class BlendingModule:
         """Laplacian-pyramid fusion (blending_module.py:369-506) -> uint8 canvas."""
         del overlap_map
         images, positions, shape = self._collect(tiles, output_shape, guess_without_shape=False)
+        rank, world = self._dist_world()
+        if world > 1 and all(im.dtype == np.uint8 for im in images) and len({im.shape[2:] for im in images}) == 1 \
+                and len({im.ndim for im in images}) == 1:
+            return self._fuse_sharded(images, positions, shape, _weight_name(weight_type), rank, world)
         return self._fuse(images, positions, shape, _weight_name(weight_type), laplacian=True)
 
     def weighted_average_fusion(self, tiles: List[Union[np.ndarray, TileInfo]],

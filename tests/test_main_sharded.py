@@ -89,3 +89,18 @@ def test_two_rank_rehearsal_equals_one_rank(tmp_path, ext):
     q2 = json.load(open(out2.rsplit(".", 1)[0] + "_qa_report.json"))
     q1.pop("timestamp"), q2.pop("timestamp")
     assert q1 == q2 and np.isfinite(q1["full_reference"]["psnr"]) and 0.0 < q1["full_reference"]["ssim"] <= 1.0
+
+
+@pytest.mark.gpu
+def test_laplacian_fusion_across_ranks(tmp_path):
+    """BlendingModule.laplacian_fusion called SPMD under an initialised process group (2 gloo ranks on the one GPU): every
+    rank blends its strip, the strips are all-gathered -- the canvas equals the one-process result byte for byte."""
+    worker = os.path.join(ROOT, "tests", "_fusion_worker.py")
+    one, two = str(tmp_path / "one.npy"), str(tmp_path / "two.npy")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r1 = subprocess.run([sys.executable, worker, one], capture_output=True, text=True, timeout=600, env=env)
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-2000:]
+    r2 = subprocess.run([sys.executable, worker, two, "--launch", "2"], capture_output=True, text=True, timeout=900, env=env)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-2000:]
+    a, b = np.load(one), np.load(two)
+    assert a.shape == b.shape == (300, 420, 3) and np.array_equal(a, b)
