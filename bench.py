@@ -73,15 +73,14 @@ def algorithmic_bytes(geo, fused: bool = None) -> dict:
         "assess_all": 6.0 * m,                                     # both u8 images once: SSE + 3 SSIM variants (one pass)
         # the reference-shaped model of SURVEY 8(d) (scatter into fp32 accumulators), for comparison
         "_survey_blend_model": 63.30 * n + 19.0 * m,
-        # the unfused design of rounds 1-2 (R_1 written and re-read): the byte count round 2's 60 % target was set on
-        "_r02_blend_design": (6.0 + 12.0 * s14 + 12.0 * s25) * n + up_all + 9.0 * n + 3.0 * m,
     }
     return out
 
 
 # bench kernel family -> prefix of the rocprofv3 kernel name(s) (template arguments change between builds: matched by prefix)
 ROCPROF_PREFIXES = {"tile_extract": ["k_tile_extract"], "down_l0": ["k_down_march<0,"], "down_l1p": ["k_down_march<2,"],
-                    "up_level": ["k_up_level_blk<"], "final_gather": ["k_final_fast<", "k_final_fused<"],
+                    "up_level": ["k_up_level_blk<"],
+                    "final_gather": ["k_final_fast<", "k_final_fused<", "k_final_march1<", "k_final_marchn<"],
                     "assess_all": ["k_assess_march<"]}
 BLEND_FAMILIES = ("down_l0", "down_l1p", "up_level", "final_gather")
 # VALU model of the fused assessment: per pixel (= per thread and row) the march issues ~223 VALU instructions
@@ -126,6 +125,18 @@ def measured_traffic() -> dict:
         acc["total_2x"] += rec["per_step"]["total_2x"]
         acc["launches_per_step"] += rec["launches_per_step"]
     return out
+
+
+def traffic_stale(traffic: dict):
+    """True when the PMC summary the `traffic` figures come from was collected on another build of the library than the one
+    loaded now (source digest compiled into libsrhip.so), None when either side is unknown."""
+    try:
+        import _native
+        now = _native.load().sr_source_digest().decode()
+    except Exception:  # noqa: BLE001
+        return None
+    then = traffic.get("_build_digest")
+    return None if not then or not now else (then != now)
 
 
 def cpu_baseline(seed_img: np.ndarray, geo_full, budget_tiles=(3, 3), repeats: int = 3) -> dict:
@@ -394,6 +405,15 @@ def run_workload(args, workload: str, steps: int, warmup: int, detailed: bool, d
         gathered = [None] * world
         dist.all_gather_object(gathered, mine)
         ranks_info = gathered
+    elif world > 1 and batch:
+        # config 4: one image per rank, nothing on the data path between them -- every rank's own line, gathered
+        mine = {"rank": rank, "image_noise_seed_offset": rank, "tiles_owned": len(geo.rects), "tiles_received": 0,
+                "exchange_bytes_in": 0, "exchange_bytes_out": 0, "collectives_on_data_path": 0,
+                "step_ms_median": round(step_ms[len(step_ms) // 2], 4),
+                "quality": {k: (v if np.isfinite(v) else str(v)) for k, v in metrics.items()}}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        ranks_info = gathered
     _stage(f"{workload}: results gathered")
 
     pcie = None
@@ -447,21 +467,30 @@ def run_workload(args, workload: str, steps: int, warmup: int, detailed: bool, d
         }
         if ranks_info is not None:
             out["ranks"] = ranks_info
-            out["config"]["strip_bounds"] = list(pipe.xplan.bounds)
+            if not batch:
+                out["config"]["strip_bounds"] = list(pipe.xplan.bounds)
         if lp_model is not None:
             out["config"]["workload"] += f" + LPIPS-{args.lpips} (synthetic weights, parity unpinned)"
             out["quality"][f"lpips_{args.lpips}_synthetic_weights"] = lp_value
         if detailed:
             kernels = {}
             share = 1.0 / world if (world > 1 and not batch) else 1.0         # each rank moves ~1/N of the bytes (+ halo)
+            parts = {}
             for name, (ms, launches) in prof.items():
                 nsteps = prof_steps
                 per_step_ms = ms / nsteps
+                if name.startswith("gather_"):                       # the launches inside final_gather (marched zones / block kernel)
+                    parts[name[len("gather_"):]] = round(per_step_ms, 4)
+                    continue
                 b = alg.get(name)
                 kernels[name] = {"ms_per_step": round(per_step_ms, 4), "launches_per_step": launches / nsteps,
                                  "timed_in": "separate sequential pass (standalone)",
                                  "alg_GB": None if b is None else round(b * share / 1e9, 4),
                                  "GBps": None if b is None or per_step_ms <= 0 else round(b * share / 1e9 / (per_step_ms / 1e3), 1)}
+            if parts and "final_gather" in kernels:
+                kernels["final_gather"]["parts_ms"] = parts
+                kernels["final_gather"]["parts_note"] = ("march<N>: column-marching kernels over the zones covered by N tiles; rest: the "
+                                                         "block kernel (border cells and what no march item takes)")
             roofline = None
             traffic = measured_traffic() if (world == 1 and workload == "200MP") else {}
             cands = [(v["ms_per_step"], k) for k, v in kernels.items() if v["alg_GB"] is not None]
@@ -488,6 +517,7 @@ def run_workload(args, workload: str, steps: int, warmup: int, detailed: bool, d
                             "traffic_calibrated": (tr["total"] / max(tr["launches_per_step"], 1)) if tr else None,
                             "traffic_source": traffic.get("_source"),
                             "traffic_build_digest": traffic.get("_build_digest"),
+                            "traffic_stale": traffic_stale(traffic),      # counters collected on another build of the library
                             "avg_launch_ms": round(per_launch_ms, 4),
                             "alg_bytes_per_launch": alg_launch,
                             "measured_in": "timed region (this kernel shares the GPU with the next image's tile stage and "
@@ -516,16 +546,22 @@ def run_workload(args, workload: str, steps: int, warmup: int, detailed: bool, d
                                   "frac": round(blend_alg / 1e9 / (blend_ms / 1e3) / HBM_PEAK_GBS, 4),
                                   "alg_bytes": blend_alg, "ms": round(blend_ms, 4),
                                   "fused_gather": fused_gather_enabled(),
-                                  "achieved_on_r02_design_bytes": round(alg["_r02_blend_design"] / div / 1e9 / (blend_ms / 1e3), 1),
-                                  "frac_on_r02_design_bytes": round(alg["_r02_blend_design"] / div / 1e9 / (blend_ms / 1e3) / HBM_PEAK_GBS, 4),
+                                  # what rocprof counted (separate --pmc passes, newest committed summary) over the same time:
+                                  # the "rocprof achieved-HBM-GB/s" of the north star
                                   "traffic": sum(t["total_2x"] for t in bt) if all(bt) else None,
                                   "traffic_calibrated": sum(t["total"] for t in bt) if all(bt) else None,
+                                  "achieved_counter_GBps": round(sum(t["total"] for t in bt) / 1e9 / (blend_ms / 1e3), 1) if all(bt) else None,
+                                  "frac_counter": round(sum(t["total"] for t in bt) / 1e9 / (blend_ms / 1e3) / HBM_PEAK_GBS, 4) if all(bt) else None,
                                   "traffic_source": traffic.get("_source"),
+                                  "traffic_stale": traffic_stale(traffic),
+                                  # SURVEY 8(d)'s contract model (scatter into fp32 accumulators: 63.30 B per tile px + 19 B per
+                                  # canvas px) priced on the same time: above 1 BY DESIGN -- this gather never materialises the fp32
+                                  # canvas, so it moves a third of those bytes; not evidence of skipped work (see `parity`)
+                                  "frac_survey_model": round(alg["_survey_blend_model"] / div / 1e9 / (blend_ms / 1e3) / HBM_PEAK_GBS, 4),
                                   "timed_in": "separate sequential pass (standalone kernels, one image at a time)",
                                   "note": "the Laplacian blend of one image (pyramid down chain, collapse, canvas gather); "
-                                          "alg_bytes is THIS design's byte model (fused gather: R_1 never leaves the CU), "
-                                          "smaller than the unfused design of round 2 (frac_on_r02_design_bytes: the same time "
-                                          "priced on that design's 10.18 GB) and than SURVEY 8(d)'s scatter model"}
+                                          "alg_bytes is THIS design's byte model (R_1 is never written: the gather forms it on the "
+                                          "fly); frac = alg_bytes / time / 8 TB/s, frac_counter the same with the bytes rocprof counted"}
             gpu_ms = sum(v["ms_per_step"] for v in kernels.values())
             total_alg = sum(alg[kk] for kk in kernels if kk in alg)
             out.update({

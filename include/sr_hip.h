@@ -332,7 +332,10 @@ SR_API int sr_ssim_u8(sr_ctx *ctx, const uint8_t *d_a, int64_t stride_a, const u
 /* The same three SSIM variants on FLOAT images (the reference passes float arrays with max > 1 on unchanged,
  * quality_assessment_module.py:169-195,351-417): dtype SR_F32 or SR_F64, cn 1 (gray as it is) or 3 (float32 only: cv2's
  * float RGB2GRAY, 0.299 R + 0.587 G + 0.114 B in fp32; cv2.cvtColor rejects float64).  float64 arithmetic throughout, like
- * skimage; a separable reference form, not a tuned kernel.  Strides in bytes. */
+ * scikit-image 0.18.3 (the version pinned here); a separable reference form, not a tuned kernel.  Strides in bytes.
+ * PARITY UNPINNED for SR_F32: scikit-image >= 0.19 (the reference asks for >= 0.21) keeps float32 inputs in float32
+ * (_supported_float_type), so its filters and SSIM algebra run in fp32 there and differ from this float64 form by about
+ * 1e-6 relative -- inside the north star's 1e-4, outside the 1e-9 the tests hold against this repository's own oracle. */
 SR_API int sr_ssim_float(sr_ctx *ctx, int dtype, const void *d_a, int64_t stride_a, const void *d_b, int64_t stride_b,
                          int h, int w, int cn, int mode, double data_range, int row_begin, int row_end, double *h_sum,
                          uint64_t *h_count);

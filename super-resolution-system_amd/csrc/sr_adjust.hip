@@ -1298,7 +1298,10 @@ int sr_color_correct_u8(sr_ctx *ctx, const uint8_t *d_img, int64_t stride, int h
         if (es2 != hipSuccess) return sr_set_error(SR_ERR_HIP, "sr_color_correct_u8: %s", hipGetErrorString(es2));
         return SR_OK;
     }
-    if (radius == CC8_R && h >= 16 && w >= 16 && !in_place && !env_flag_off("SR_CC_FUSED")) {
+    // (the fused kernel's division leaves out v_div_scale / v_div_fixup, the identity while var + eps stays in [0.006, 65026]:
+    // true for the reference's eps = 0.01, not for an arbitrary one -- a smaller eps takes the pass-structured kernels and
+    // their IEEE division, so results never depend on which kernels run)
+    if (radius == CC8_R && h >= 16 && w >= 16 && !in_place && eps >= 0.005f && !env_flag_off("SR_CC_FUSED")) {
         // the reference's setting with an integer-valued guide table (histogram matching, method 'none'): one fused kernel
         unsigned char tabb[4 * 256];
         bool whole = true;

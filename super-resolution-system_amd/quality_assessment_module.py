@@ -257,7 +257,13 @@ class QualityAssessmentModule:
             if a.dtype not in (np.uint8, np.float32) or b.dtype not in (np.uint8, np.float32):
                 raise ValueError("calculate_ssim: cv2.cvtColor(RGB2GRAY) supports 8-bit, 16-bit and float32 images only "
                                  f"(got {a.dtype} / {b.dtype}); 16-bit RGB is not on the HIP path")
-            dt, code = np.float32, _native.SR_F32          # a u8 partner of a float32 image is converted (values exact)
+            if a.dtype != b.dtype:
+                # cv2.cvtColor grays each image in its OWN dtype (quality_assessment_module.py:359-360): the uint8 partner gets
+                # the rounded fixed-point gray, the float32 one the float formula -- two gray planes up to 0.5 level apart.
+                # sr_ssim_float grays both with the float formula, so the mixed pair is refused rather than answered differently.
+                raise NotImplementedError("calculate_ssim: one RGB image is uint8 and the other float32 after preprocessing; "
+                                          "the HIP path takes RGB pairs of one dtype (convert one of them)")
+            dt, code = np.float32, _native.SR_F32
         else:
             dt, code = (np.float32, _native.SR_F32) if (a.dtype == np.float32 and b.dtype == np.float32) else (np.float64, _native.SR_F64)
         a = np.ascontiguousarray(a, dtype=dt)

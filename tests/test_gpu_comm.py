@@ -229,3 +229,52 @@ def test_bench_two_rank_rehearsal_matches_one_rank():
     assert [r["rank"] for r in two["ranks"]] == [0, 1]
     assert sum(r["exchange_bytes_in"] for r in two["ranks"]) == sum(r["exchange_bytes_out"] for r in two["ranks"]) > 0
     assert all(r["strip_rows"] == [b[i], b[i + 1]] for i, r in enumerate(two["ranks"]))
+
+
+def _bench_json(extra_env, args, timeout=900):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    common = ["--steps", "2", "--warmup", "1", "--sweep", "none", "--no-pcie", "--no-cpu-baseline"]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args + common, env={**env, **extra_env},
+                       capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_rank_batch_rehearsal_150mp():
+    """BASELINE config 4 (batch of images at 150 MP, one per GPU, no RCCL on the data path) with two gloo ranks on this GPU
+    (launcher + 2 ranks = 3 processes): weak scaling, every rank's own line gathered, no exchange bytes, and rank 0's
+    scores are exactly the one-rank run's (its image is the same)."""
+    two = _bench_json({"SR_DIST_BACKEND": "gloo"}, ["--gpus", "2", "--mode", "batch", "--workload", "150MP", "--deadline-s", "800"])
+    one = _bench_json({}, ["--gpus", "1", "--workload", "150MP"])
+    assert two["n_gpus"] == 2 and two["config"]["parallelism"] == "batch2" and two["scaling"] == "weak"
+    assert "REHEARSAL" in two["data"]
+    assert [r["rank"] for r in two["ranks"]] == [0, 1]
+    assert all(r["exchange_bytes_in"] == 0 and r["exchange_bytes_out"] == 0 and r["collectives_on_data_path"] == 0 for r in two["ranks"])
+    assert two["ranks"][0]["quality"] == one["quality"] == two["quality"]
+    assert two["ranks"][1]["quality"]["psnr"] != one["quality"]["psnr"]          # the second rank's image is another noise draw
+    assert "strip_bounds" not in two["config"]
+
+
+def test_bench_two_rank_strips_rehearsal_200mp_kd():
+    """BASELINE config 5's geometry (non-uniform k-d tiling of the 200 MP canvas) in strips over two gloo ranks on this GPU:
+    the scores equal the one-rank run (PSNR exactly, SSIM to the summation order), every tile has an owner, the rows
+    that cross the strip boundary are a small part of the tiles."""
+    two = _bench_json({"SR_DIST_BACKEND": "gloo"}, ["--gpus", "2", "--workload", "200MP-kd", "--deadline-s", "800"])
+    one = _bench_json({}, ["--gpus", "1", "--workload", "200MP-kd"])
+    assert two["n_gpus"] == 2 and two["config"]["parallelism"] == "strips2" and two["scaling"] == "strong"
+    assert two["quality"]["psnr"] == one["quality"]["psnr"]
+    for k in ("ssim_uniform", "ssim_gauss", "ssim_simple"):
+        assert two["quality"][k] == pytest.approx(one["quality"][k], rel=1e-12)
+    b = two["config"]["strip_bounds"]
+    assert b[0] == 0 and b[-1] == 11550 and len(b) == 3
+    assert sum(r["tiles_owned"] for r in two["ranks"]) == 32
+    moved = sum(r["exchange_bytes_in"] for r in two["ranks"])
+    assert 0 < moved == sum(r["exchange_bytes_out"] for r in two["ranks"]) < 0.25 * two["config"]["tile_pixels"] * 3

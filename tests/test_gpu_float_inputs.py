@@ -66,6 +66,9 @@ def test_merge_tiles_float_tile_data(rng, tmp_path):
 
 @pytest.mark.parametrize("branch,multiscale,mode", [("A", True, "gauss"), ("A", False, "uniform"), ("B", True, "simple")])
 def test_calculate_ssim_float_images(rng, branch, multiscale, mode):
+    """Float images that stay float after _preprocess_image (quality_assessment_module.py:169-195,351-417).
+    PARITY UNPINNED for float32 pairs: the 1e-9 here is against this repository's float64 oracle (= scikit-image 0.18.3's
+    promotion); scikit-image >= 0.19 computes float32 inputs in float32 and differs by about 1e-6 (include/sr_hip.h)."""
     import quality_assessment_module as qam
     q = qam.QualityAssessmentModule(device='cpu', ssim_branch=branch)
     a8, b8 = _img(rng, 97, 131), _img(rng, 97, 131)
@@ -86,3 +89,18 @@ def test_calculate_ssim_float_images(rng, branch, multiscale, mode):
     # float64 RGB: cv2.cvtColor has no such conversion
     with pytest.raises(ValueError):
         q.calculate_ssim(a8.astype(np.float64) * 1.5, b8.astype(np.float64), multiscale=multiscale)
+
+
+def test_calculate_ssim_mixed_u8_float_rgb_is_refused(rng):
+    """cv2.cvtColor grays a uint8 image with the rounded fixed-point formula and a float32 one with the float formula
+    (quality_assessment_module.py:359-360); sr_ssim_float has one formula for both planes, so the mixed RGB pair is refused
+    instead of being answered up to half a grey level per pixel differently."""
+    from quality_assessment_module import QualityAssessmentModule
+    qa = QualityAssessmentModule()
+    a = rng.integers(0, 256, (40, 52, 3), dtype=np.uint8)
+    b = a.astype(np.float32) + 1.5                     # max > 1: stays float after _preprocess_image
+    with pytest.raises(NotImplementedError):
+        qa.calculate_ssim(a, b)
+    with pytest.raises(NotImplementedError):
+        qa.calculate_ssim(b, a, multiscale=False)
+    assert 0.0 < qa.calculate_ssim(b, b + 1.0) <= 1.0  # one dtype: answered
