@@ -306,6 +306,11 @@ class DevicePipeline:
         self.main_stream = torch.cuda.current_stream(self.dev)
         self.qa_stream = torch.cuda.Stream(self.dev)
         self.qa_ctx = _native.Context(self.device, stream=self.qa_stream.cuda_stream)
+        import os as _os
+        self._assess_split = _os.environ.get("SR_ASSESS_SPLIT", "0") == "1"
+        self._qa_gate = _os.environ.get("SR_QA_GATE", "0") == "1"
+        self._gated = None
+        self._results_u = None
         self._e_qa = [None, None]         # assessment of the image in canvas slot j has finished
         self._slot = 0                    # canvas / result slot of the image in progress
         self.plan = _native.BlendPlan(self.ctx, geo.rects, cn, geo.canvas_h, geo.canvas_w, geo.levels,
@@ -387,6 +392,16 @@ class DevicePipeline:
                           ("simple", _native.ASSESS_SIMPLE)):
             if mode in self.ssim_modes:
                 flags |= bit
+        if self._assess_split and (flags & _native.ASSESS_UNIFORM7) and (flags & ~(_native.ASSESS_UNIFORM7 | _native.ASSESS_SSE)):
+            # A/B arm (SR_ASSESS_SPLIT=1, profiles/r04_assess_split.json): the Gaussian(+SSE) variant of the march (no
+            # uniform-7 ring: 128 registers, four blocks per CU) and the integer uniform-7 variant as two launches
+            if self._results_u is None:
+                self._results_u = [self.torch.zeros(4, dtype=self.torch.float64, device=self.dev) for _ in range(2)]
+            args = (reference.data_ptr(), reference.stride(0), canvas.data_ptr(), canvas.stride(0), g.canvas_h, g.canvas_w, g.cn)
+            ctx.assess_u8_async(*args, self.results_bufs[slot].data_ptr(), flags=flags & ~_native.ASSESS_UNIFORM7, row_begin=s0, row_end=s1)
+            ctx.assess_u8_async(*args, self._results_u[slot].data_ptr(), flags=_native.ASSESS_UNIFORM7, row_begin=s0, row_end=s1)
+            self.results_bufs[slot][1:2].copy_(self._results_u[slot][1:2])     # torch's current stream is the context's here
+            return
         ctx.assess_u8_async(reference.data_ptr(), reference.stride(0), canvas.data_ptr(), canvas.stride(0),
                             g.canvas_h, g.canvas_w, g.cn, self.results_bufs[slot].data_ptr(), flags=flags,
                             row_begin=s0, row_end=s1)
@@ -457,6 +472,29 @@ class DevicePipeline:
         # communicator run in posting order, and an all-reduce posted right after its assessment would sit in front of
         # this exchange until that assessment (still running beside this image's blend) has finished.
         self._post_deferred_reduce()
+        if self._qa_gate and self.world == 1:
+            # Schedule experiment (SR_QA_GATE=1, profiles/r04_qa_gate.json): the previous image's assessment is released
+            # only when THIS image's pyramids are done, so the fp64-bound assessment starts beside the (memory-bound,
+            # marched) gather and runs on beside the next image's tile stage and pyramids.
+            self.plan.pyramids(ptrs, self._strides, list(range(len(self.geo.rects))), first=True)
+            pyr_done = torch.cuda.Event()
+            pyr_done.record(self.main_stream)
+            self._release_gated(pyr_done)
+            if self._e_qa[j] is not None:
+                self.main_stream.wait_event(self._e_qa[j])
+            canvas = self.canvases[j]
+            self.plan.gather(ptrs, self._strides, canvas.data_ptr(), canvas.stride(0))
+            blended = torch.cuda.Event()
+            blended.record(self.main_stream)
+            self._gated = (reference, j, blended)
+            self._deferred = None
+            if next_image is not None:
+                self.stage_tile(next_image, nk)
+                self._pending = self.stage_exchange(nk)
+            else:
+                self._pending = None
+            self._done, self._cur, self._slot = j, nk, 1 - j
+            return
         if self._e_qa[j] is not None:                     # canvas slot j: its previous image has been assessed
             self.main_stream.wait_event(self._e_qa[j])
         self._finish_blend(k, staged, j)
@@ -477,6 +515,21 @@ class DevicePipeline:
             self._pending = None
         self._done, self._cur, self._slot = j, nk, 1 - j
 
+    def _release_gated(self, after=None):
+        """SR_QA_GATE: queue the held assessment on the second stream, behind `after` (an event of the main stream)."""
+        if self._gated is None:
+            return
+        torch = self.torch
+        reference, j, blended = self._gated
+        self._gated = None
+        with torch.cuda.stream(self.qa_stream):
+            self.qa_stream.wait_event(blended)
+            if after is not None:
+                self.qa_stream.wait_event(after)
+            self.stage_assess(reference, j, self.qa_ctx)
+            self._e_qa[j] = torch.cuda.Event()
+            self._e_qa[j].record(self.qa_stream)
+
     def _post_deferred_reduce(self):
         j = self._deferred
         if j is None:
@@ -496,6 +549,7 @@ class DevicePipeline:
 
     def pipeline_finish(self):
         """Joins the second stream: after this the main stream (and a device synchronise) see every image's sums."""
+        self._release_gated()
         self._post_deferred_reduce()
         for j in (0, 1):
             for w in self._reduce_work[j]:
