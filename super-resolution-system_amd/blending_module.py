@@ -375,15 +375,27 @@ class BlendingModule:
         """Windowed SSIM between the fused canvas and every source tile (blending_module.py:765-853); the window
         scan runs on the GPU (sr_seam_scan), grouping of adjacent hits follows :905-967 on the host."""
         result = np.ascontiguousarray(result)
+
+        def not_u8(img: np.ndarray, what: str):
+            """What the reference does with a non-uint8 image here (pinned by tests/test_host_modules.py): _compute_ssim
+            sends a 3-D window through cv2.cvtColor(BGR2GRAY) (blending_module.py:873-876), which takes 8-bit, 16-bit and
+            float32 data and raises cv2.error for every other depth -- mirrored as ValueError (cv2 is absent; the QA mirror
+            does the same for float64 RGB).  What cv2 would take (uint16 / float32 colour, any 2-D gray, which only goes
+            through astype(float64)) is not on the HIP path: NotImplementedError, never a silent other answer."""
+            if img.ndim == 3 and img.dtype not in (np.uint16, np.float32):
+                raise ValueError(f"detect_seams: cv2.cvtColor(BGR2GRAY) supports 8-bit, 16-bit and float32 images only "
+                                 f"({what} is {img.dtype})")
+            raise NotImplementedError(f"detect_seams: uint8 {what} only on the HIP path (got {img.dtype})")
+
         if result.dtype != np.uint8:
-            raise NotImplementedError("detect_seams: uint8 canvas only")
+            not_u8(result, "canvas")
         infos = [t if isinstance(t, TileInfo) else TileInfo(np.asarray(t), 0, 0, 0, 0) for t in tiles]
         cn = result.shape[2] if result.ndim == 3 else 1
         keep = []
         for ti in infos:
             img = np.asarray(ti.image)
             if img.dtype != np.uint8:
-                raise NotImplementedError("detect_seams: uint8 tiles only")
+                not_u8(img, "tiles")
             if (img.ndim == 3) != (result.ndim == 3) or (img.ndim == 3 and img.shape[2] != cn):
                 continue                                  # result_roi.shape != tile_roi.shape -> skipped by the reference
             keep.append((np.ascontiguousarray(img), int(ti.x), int(ti.y)))
@@ -474,6 +486,10 @@ class BlendingModule:
         img = np.ascontiguousarray(image)
         ref = np.ascontiguousarray(reference_tile)
         if img.dtype != np.uint8 or ref.dtype != np.uint8:
+            # the reference takes any numeric dtype here (astype(float32), :1002-1003; the histogram table is indexed with
+            # astype(uint8) of the float values, :1052-1055): accepted there, not on the HIP path -- refused, not approximated
+            if img.dtype.kind not in "uifb" or ref.dtype.kind not in "uifb":
+                raise TypeError(f"color_correction: cannot convert {img.dtype} / {ref.dtype} images to float32")      # numpy's astype error
             raise NotImplementedError("color_correction: uint8 images only on the HIP path")
         cn = img.shape[2] if img.ndim == 3 else 1
         rcn = ref.shape[2] if ref.ndim == 3 else 1

@@ -4148,8 +4148,9 @@ static int blend_gather(sr_blend_plan *P, bool lap, int dtype, void *const *h_d_
             // the marched zones first (long work items), then the edge and regular blocks of what is left; float tiles take
             // the regular blocks everywhere
             const bool marched = dtype == SR_U8 && P->n_march_total > 0;
-            // The marched zones and the block kernel write disjoint cells of the canvas: they run beside each other, the
-            // marched kernels on the context's side streams (forked off its stream here, joined below) with SR_GATHER_STREAMS=1; default:
+            // The marched zones and the block kernel write disjoint cells of the canvas: with SR_GATHER_STREAMS=1 the small,
+            // latency-bound launches (3- / 4-tile zones, the block kernel) run on the context's side streams (forked off its
+            // stream here, joined below) beside the large 1- and 2-tile ones; default:
             // one after the other on the context's stream (per-kernel timing).
             static const bool side_ok = std::getenv("SR_GATHER_STREAMS") && std::getenv("SR_GATHER_STREAMS")[0] == '1';
             bool forked = false;
@@ -4174,14 +4175,14 @@ static int blend_gather(sr_blend_plan *P, bool lap, int dtype, void *const *h_d_
             if (dtype == SR_U8 && P->n_march_items[1] > 0) {
                 ProfScope ps2(ctx, "gather_march1");
                 if (P->cn == 3)
-                    hipLaunchKernelGGL((k_final_march1<3>), dim3((unsigned)P->n_march_items[1]), dim3(64), 0, ms[1], P->d_march_items[1],
+                    hipLaunchKernelGGL((k_final_march1<3>), dim3((unsigned)P->n_march_items[1]), dim3(64), 0, ms[0], P->d_march_items[1],
                                        P->d_fdesc, P->d_arena, arena_bytes, P->d_luts, d_canvas, (long long)canvas_stride, d_canvas_f32, P->canvas_w);
                 else
-                    hipLaunchKernelGGL((k_final_march1<1>), dim3((unsigned)P->n_march_items[1]), dim3(64), 0, ms[1], P->d_march_items[1],
+                    hipLaunchKernelGGL((k_final_march1<1>), dim3((unsigned)P->n_march_items[1]), dim3(64), 0, ms[0], P->d_march_items[1],
                                        P->d_fdesc, P->d_arena, arena_bytes, P->d_luts, d_canvas, (long long)canvas_stride, d_canvas_f32, P->canvas_w);
             }
 #define LAUNCH_MARCHN(CNV, NTV)                                                                                          \
-    hipLaunchKernelGGL((k_final_marchn<CNV, NTV>), dim3((unsigned)P->n_march_items[NTV]), dim3(64 * NTV), 0, ms[2],           \
+    hipLaunchKernelGGL((k_final_marchn<CNV, NTV>), dim3((unsigned)P->n_march_items[NTV]), dim3(64 * NTV), 0, ms[NTV == 2 ? 0 : 1],  \
                        P->d_march_items[NTV], P->d_fdesc, P->d_arena, arena_bytes, P->d_luts, d_canvas,                      \
                        (long long)canvas_stride, d_canvas_f32, P->canvas_w)
             static_assert(MARCH_NT == 4, "the tile counts launched here");
@@ -4192,15 +4193,12 @@ static int blend_gather(sr_blend_plan *P, bool lap, int dtype, void *const *h_d_
                 else            { if (nt == 2) LAUNCH_MARCHN(1, 2); else if (nt == 3) LAUNCH_MARCHN(1, 3); else LAUNCH_MARCHN(1, 4); }
             }
 #undef LAUNCH_MARCHN
-            if (forked) {
-                for (int i = 0; i < 2; ++i) HIPCHK(hipEventRecord(ctx->side_join[i], ctx->side[i]));
-            }
             const long long n_reg = marched ? P->n_freg : P->n_freg_all;
             const int *reg_list = marched ? P->d_freg_list : P->d_freg_all;
             ProfScope ps3(ctx, "gather_rest");
             dim3 grid((unsigned)std::max<long long>(n_edge + n_reg, 1)), blk1(FU_THREADS);
 #define LAUNCH_FUSED(DT, CNV)                                                                                          \
-    hipLaunchKernelGGL((k_final_fused<DT, CNV>), grid, blk1, 0, ctx->stream, P->d_fdesc, P->d_fcand_off, P->d_fcand_idx,  \
+    hipLaunchKernelGGL((k_final_fused<DT, CNV>), grid, blk1, 0, ms[2], P->d_fdesc, P->d_fcand_off, P->d_fcand_idx,  \
                        P->d_fedge_blocks, P->d_fedge_cand, n_edge, nbx_r, reg_list, P->d_arena, P->d_luts, d_canvas,   \
                        (long long)canvas_stride, d_canvas_f32, P->canvas_w, P->row_begin, P->row_end)
             if (n_edge + n_reg > 0) {
@@ -4209,6 +4207,7 @@ static int blend_gather(sr_blend_plan *P, bool lap, int dtype, void *const *h_d_
             }
 #undef LAUNCH_FUSED
             if (forked) {
+                for (int i = 0; i < 2; ++i) HIPCHK(hipEventRecord(ctx->side_join[i], ctx->side[i]));
                 for (int i = 0; i < 2; ++i) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->side_join[i], 0));
             }
         } else if (P->cn == 3 || P->cn == 1) {

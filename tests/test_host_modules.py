@@ -154,3 +154,28 @@ def test_mean_std_table_vs_reference_float32_expression():
     assert int(diff.max()) <= 1
     values_flipped = {int(v) for c in range(3) for v in np.unique(src[..., c][diff[..., c] != 0])}
     assert len(values_flipped) <= 24 and float((diff != 0).mean()) < 0.10
+
+
+def test_non_u8_seams_and_color_correction_raise_pinned_types():
+    """Inputs the HIP path does not take are refused before any device call, with the exception the reference's own calls
+    pin: cv2.cvtColor(BGR2GRAY) (blending_module.py:873-876) rejects colour windows that are not 8-bit / 16-bit / float32
+    -> ValueError here (cv2.error is not importable); what cv2 / numpy would accept -> NotImplementedError."""
+    import numpy as np
+    from blending_module import BlendingModule, TileInfo
+    bm = BlendingModule()
+    u8 = np.zeros((32, 32, 3), np.uint8)
+    for bad in (np.float64, np.int32):
+        with pytest.raises(ValueError):
+            bm.detect_seams(u8.astype(bad), [TileInfo(u8, 0, 0, 0, 0)])
+        with pytest.raises(ValueError):
+            bm.detect_seams(u8, [TileInfo(u8.astype(bad), 0, 0, 0, 0)])
+    for ok_in_cv2 in (np.float32, np.uint16):
+        with pytest.raises(NotImplementedError):
+            bm.detect_seams(u8.astype(ok_in_cv2), [TileInfo(u8, 0, 0, 0, 0)])
+    with pytest.raises(NotImplementedError):
+        bm.detect_seams(np.zeros((32, 32), np.float64), [TileInfo(np.zeros((32, 32), np.uint8), 0, 0, 0, 0)])   # gray: astype only
+    with pytest.raises(NotImplementedError):
+        bm.color_correction(u8.astype(np.float32), u8)
+    with pytest.raises(NotImplementedError):
+        bm.color_correction(u8, u8.astype(np.int16), method="mean_std")
+    assert bm.color_correction(u8.astype(np.float64), u8, method="none").dtype == np.float64                     # 'none' returns the input
