@@ -465,6 +465,11 @@ def run_workload(args, workload: str, steps: int, warmup: int, detailed: bool, d
                         "max": round(step_ms[-1], 4), "clock": "HIP events on the main stream between consecutive images, rank 0"},
             "quality": {k: (v if np.isfinite(v) else str(v)) for k, v in metrics.items()},
         }
+        try:
+            import _native
+            out["build_digest"] = _native.load().sr_source_digest().decode()      # the library this line was measured on
+        except Exception:  # noqa: BLE001
+            out["build_digest"] = None
         if ranks_info is not None:
             out["ranks"] = ranks_info
             if not batch:

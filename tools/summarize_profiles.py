@@ -114,10 +114,17 @@ if fam in fam_tot:
     roof["traffic_calibrated"] = sum(rec["per_step"]["total"] for k, rec in out["kernels"].items()
                                      if bench_mod.family_of(k) == fam) / max(lps, 1)
     roof["traffic_source"], roof["traffic_build_digest"] = f"{prefix}_traffic.json", out["build_digest"]
+    roof["traffic_stale"] = (bench.get("build_digest") != out["build_digest"]) if bench.get("build_digest") else None
 rb = bench.get("roofline_blend") or {}
 if rb and all(f in fam_tot for f in bench_mod.BLEND_FAMILIES):
     rb["traffic"] = sum(fam_tot[f] for f in bench_mod.BLEND_FAMILIES)
+    rb["traffic_calibrated"] = sum(rec["per_step"]["total"] for k, rec in out["kernels"].items()
+                                   if bench_mod.family_of(k) in bench_mod.BLEND_FAMILIES)
+    if rb.get("ms"):
+        rb["achieved_counter_GBps"] = round(rb["traffic_calibrated"] / 1e9 / (rb["ms"] / 1e3), 1)
+        rb["frac_counter"] = round(rb["achieved_counter_GBps"] / bench_mod.HBM_PEAK_GBS, 4)
     rb["traffic_source"] = f"{prefix}_traffic.json"
+    rb["traffic_stale"] = (bench.get("build_digest") != out["build_digest"]) if bench.get("build_digest") else None
 json.dump(bench, open(f"profiles/{prefix}_bench.json", "w"), indent=1)
 for f in glob.glob(f"{run}/bench_*.json"):
     name = os.path.basename(f)

@@ -38,20 +38,29 @@ __global__ __launch_bounds__(256) void k(double *out, int seed)
 }
 template <int OP> void run(const char *name, double *d)
 {
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    const int blocks = 256 * 8;   // 8 blocks x 4 waves per CU = 8 waves / SIMD
-    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d, 1);
-    hipEventRecord(e0);
-    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d, 1);
-    hipEventRecord(e1); hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1);
-    const double winstr = (double)blocks * 4 * N_IT * REP * 4;       // wave-instructions
-    const double per_simd = winstr / 1024.0;
-    printf("%-16s %8.3f ms  -> %.2f cycles / wave-instr / SIMD (at 2.4 GHz)\n", name, ms, ms * 1e-3 * 2.4e9 / per_simd);
+    // one launch per occupancy: w blocks of 4 waves per CU = w waves per SIMD (1, 2, 4, 8); cycles of a SIMD per wave-instruction
+    // issued to it (N_IT x REP x 4 instructions per wave).  4.0 at every occupancy = a wave's VALU instruction holds its SIMD
+    // for four cycles whatever the type (the guide's `v_fma_f32 2 cyc` is a rate this stream of dependent-free
+    // instructions does not reach on gfx950).
+    printf("%-16s", name);
+    for (int w = 1; w <= 8; w *= 2) {
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        const int blocks = 256 * w;
+        hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d, 1);
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d, 1);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        const double winstr = (double)blocks * 4 * N_IT * REP * 4;       // wave-instructions
+        const double per_simd = winstr / 1024.0;
+        printf("  %d w/SIMD: %7.3f ms %5.2f cyc", w, ms, ms * 1e-3 * 2.4e9 / per_simd);
+    }
+    printf("   (cycles per wave-instruction and SIMD at 2.4 GHz)\n");
 }
 int main()
 {
-    double *d; hipMalloc(&d, 256 * 8 * 256 * 8);
+    double *d; (void)hipMalloc(&d, 256 * 8 * 256 * 8);
     run<0>("v_fma_f64", d); run<1>("v_add_f64", d); run<2>("v_mul_f64", d); run<3>("v_mul_lo_u32", d);
     run<4>("v_mul_u32_u24", d); run<5>("v_cvt_f64_i32", d); run<6>("v_rcp_f64", d); run<7>("v_add_u32", d);
     run<8>("ds_read_u8", d); run<9>("ds_read_b32", d); run<10>("v_pk_fma_f32", d); run<11>("v_fma_f32", d);
