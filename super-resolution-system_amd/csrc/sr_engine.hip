@@ -1453,8 +1453,8 @@ __device__ __forceinline__ void fused_load_pixels(const FinalDesc &D, int lx0, i
 }
 
 template <int DT, int CN, bool XO, bool YO, bool CODD>
-__device__ __forceinline__ void fused_gather_fast(const FinalDesc &D, const float *__restrict__ luts, const float *lds, int R0, int C0,
-                                                  int lx0, int ly0, const CellPixels<DT, CN> &cp, float (&acc)[2][4][CN],
+__device__ __forceinline__ void fused_gather_fast(const FinalDesc &D, const float *__restrict__ luts, const float *lds, int LP, int R0,
+                                                  int C0, int lx0, int ly0, const CellPixels<DT, CN> &cp, float (&acc)[2][4][CN],
                                                   float (&wacc)[2][4])
 {
     const bool pyr = D.nl > 1;
@@ -1477,14 +1477,14 @@ __device__ __forceinline__ void fused_gather_fast(const FinalDesc &D, const floa
     if (pyr) {
         const int r0 = (ly0 - 1) >> 1, c0 = (lx0 - 1) >> 1;
         // (g, r) pairs of rows r0 .. r0 + 2, columns c0 .. c0 + 3: 32 contiguous bytes per row
-        const float *base = lds + ((r0 - R0) * FU_LP + (c0 - C0)) * 2;
+        const float *base = lds + ((r0 - R0) * LP + (c0 - C0)) * 2;
 #pragma unroll
         for (int c = 0; c < CN; ++c) {
             const float *p = base + c * (2 * FU_PLANE);
             f2_t q[3][4], u[2][4];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                const float *pr = p + r * (2 * FU_LP);
+                const float *pr = p + r * (2 * LP);
                 if (!CODD) {
                     const f4_t a = *(const f4_t *)pr, b = *(const f4_t *)(pr + 4);
                     q[r][0].x = a.x; q[r][0].y = a.y; q[r][1].x = a.z; q[r][1].y = a.w;
@@ -1628,7 +1628,33 @@ __device__ __forceinline__ void fused_edge_block(const FinalDesc *__restrict__ d
         if (win) fused_stage1<CN>(D, arena, lds, R0, C0, npr, npc, LP, tid);
         __syncthreads();
         const int lx0 = x0 - D.x, ly0 = y0 - D.y;
-        if (edge && !(lx0 + nx <= 0 || ly0 + ny <= 0 || lx0 >= D.w || ly0 >= D.h)) {
+        const bool touches = edge && !(lx0 + nx <= 0 || ly0 + ny <= 0 || lx0 >= D.w || ly0 >= D.h);
+        // An edge cell has a border visit of SOME tile; its visits of the other tiles are mostly interior ones (the cell
+        // lies on tile A's edge and well inside tile B): those take the regular blocks' packed path (same arithmetic, same
+        // results), only the border visits pay for the per-pixel border rules.  Along a tile edge the split is uniform per
+        // tile, so a wave rarely runs both.
+        const bool inner = DT == SRC_U8 && touches && visit_is_interior<true>(D, lx0, ly0, nx, ny);    // (float tiles: generic path only)
+        if constexpr (DT == SRC_U8) if (inner) {
+            CellPixels<DT, CN> cp;
+            fused_load_pixels<DT, CN>(D, lx0, ly0, cp);
+            const bool xo = (D.x & 1) != 0;
+            const bool yo = ((row_begin - D.y) & 1) != 0;
+            const bool codd = D.nl > 1 && (((((eb.x - D.x) - 1) >> 1) - C0) & 1) != 0;
+#define FE_CALL(XOV, YOV, CV) fused_gather_fast<DT, CN, XOV, YOV, CV>(D, luts, lds, LP, R0, C0, lx0, ly0, cp, acc, wacc)
+            if (!codd) {
+                if (!xo && !yo) FE_CALL(false, false, false);
+                else if (xo && !yo) FE_CALL(true, false, false);
+                else if (!xo && yo) FE_CALL(false, true, false);
+                else FE_CALL(true, true, false);
+            } else {
+                if (!xo && !yo) FE_CALL(false, false, true);
+                else if (xo && !yo) FE_CALL(true, false, true);
+                else if (!xo && yo) FE_CALL(false, true, true);
+                else FE_CALL(true, true, true);
+            }
+#undef FE_CALL
+        }
+        if (touches && !inner) {
             unsigned valid = 0;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -1674,13 +1700,9 @@ __global__ __launch_bounds__(FU_THREADS, FU_WAVES) void k_final_fused(const Fina
     const int c_begin = cand_off[blk], c_end = cand_off[blk + 1];
     const int tid = threadIdx.x;
     const int bx0 = bx * FU_BW, by0 = row_begin + by * FU_BH;
-    const int x0 = bx0 + (tid & 31) * 4, y0 = by0 + (tid >> 5) * 2;
-    const int nx = min(4, cw - x0), ny = min(2, row_end - y0);
-    // a cell with any border visit belongs to the edge blocks (which recompute every visit of it): it stops
-    // accumulating at its first border visit and stores nothing
-    bool alive = x0 < cw && y0 < row_end && !(((unsigned)rl[1 + (tid >> 5)] >> (tid & 31)) & 1u);
     // the cells that are left span a sub-rectangle of the block (thin bands along the marched zones, mostly): the level-1
-    // window is built for that rectangle only (block-uniform: scalar arithmetic on the mask words)
+    // window is built for that rectangle only, and the threads are dealt over ITS cells (a band of 3 x 8 cells is one
+    // wave's work, not a few lanes of each of the four) -- block-uniform: scalar arithmetic on the mask words
     int sbx = bx0, sby = by0, sbw = FU_BW, sbh = FU_BH;
     {
         const int ncol = min(32, (cw - bx0 + 3) >> 2), nrow = min(FU_BH / 2, (row_end - by0 + 1) >> 1);
@@ -1704,6 +1726,14 @@ __global__ __launch_bounds__(FU_THREADS, FU_WAVES) void k_final_fused(const Fina
             sbh = 2 * (cy1 - cy0 + 1);
         }
     }
+    const int scw = sbw >> 2;                                        // cells across the sub-rectangle
+    const int scy = tid / scw, scx = tid - scy * scw;
+    const int x0 = sbx + scx * 4, y0 = sby + scy * 2;
+    const int nx = min(4, cw - x0), ny = min(2, row_end - y0);
+    const int mrow = (y0 - by0) >> 1, mcol = (x0 - bx0) >> 2;         // the cell's place in the block's mask
+    // a cell with any border visit belongs to the edge blocks (which recompute every visit of it): it stops
+    // accumulating at its first border visit and stores nothing
+    bool alive = scy < (sbh >> 1) && x0 < cw && y0 < row_end && !(((unsigned)rl[1 + min(mrow, FU_BH / 2 - 1)] >> mcol) & 1u);
     float acc[2][4][CN], wacc[2][4];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -1729,7 +1759,7 @@ __global__ __launch_bounds__(FU_THREADS, FU_WAVES) void k_final_fused(const Fina
             const bool xo = (D.x & 1) != 0;                      // x0 is a multiple of 4
             const bool yo = ((row_begin - D.y) & 1) != 0;        // y0 - row_begin is a multiple of 2
             const bool codd = D.nl > 1 && ((((lxa - 1) >> 1) - C0) & 1) != 0;   // parity of every cell's first tap column (block-uniform)
-#define FU_CALL(XOV, YOV, CV) fused_gather_fast<DT, CN, XOV, YOV, CV>(D, luts, lds, R0, C0, lx0, ly0, cp, acc, wacc)
+#define FU_CALL(XOV, YOV, CV) fused_gather_fast<DT, CN, XOV, YOV, CV>(D, luts, lds, FU_LP, R0, C0, lx0, ly0, cp, acc, wacc)
             if (!codd) {
                 if (!xo && !yo) FU_CALL(false, false, false);
                 else if (xo && !yo) FU_CALL(true, false, false);
