@@ -54,6 +54,12 @@ def fused_gather_enabled() -> bool:
     return os.environ.get("SR_FUSED_FINAL", "1")[:1] != "0"
 
 
+def down2_enabled() -> bool:
+    """The library's default for u8 RGB tiles: levels 1 and 2 of the Gaussian pyramid out of one march (k_down2_march);
+    SR_DOWN2=0 selects the two launches of round 3."""
+    return os.environ.get("SR_DOWN2", "1")[:1] != "0"
+
+
 def algorithmic_bytes(geo, fused: bool = None) -> dict:
     """Bytes each kernel family must move per step (DESIGN.md 'kernels and their rooflines').  With the fused gather
     (round 3) R_1 is never written or read: the collapse chain stops at level 2 and the gather reads G_1, W_1, G_2, R_2."""
@@ -62,11 +68,14 @@ def algorithmic_bytes(geo, fused: bool = None) -> dict:
     s14 = sum(4.0 ** -i for i in range(1, 5))
     s24 = sum(4.0 ** -i for i in range(2, 5))
     s25 = sum(4.0 ** -i for i in range(2, 6))
+    s35 = sum(4.0 ** -i for i in range(3, 6))
+    d2 = down2_enabled()
     up_all = (34.0 * s14 + 28.0 * 4.0 ** -5) * n                      # G_i, G_i+1/4, R_i+1/4, W_i in; R_i out, levels 5..1
     out = {
         "tile_extract": 6.0 * n,                                   # 3 B read + 3 B write per tile px
-        "down_l0": 6.0 * n,                                        # u8 in (3) + G1 out (12/4)
-        "down_l1p": (12.0 * s14 + 12.0 * s25) * n,                 # G1..G4 in, G2..G5 out
+        # u8 in (3) + G1 out (12/4); round 4's march also writes G2 (12/16) and G1 is never read back for it
+        "down_l0": (6.75 if d2 else 6.0) * n,
+        "down_l1p": (12.0 * s24 + 12.0 * s35) * n if d2 else (12.0 * s14 + 12.0 * s25) * n,     # G2..G4 (G1..G4) in, G3..G5 (G2..G5) out
         "up_level": (34.0 * s24 + 28.0 * 4.0 ** -5) * n if fused else up_all,       # fused: levels 5..2 only
         # fused: u8 tile 3 + G_1 12/4 + W_1 4/4 + (G_2 + R_2) 24/16 per tile px in; u8 canvas out
         "final_gather": (3.0 + 3.0 + 1.0 + 1.5) * n + 3.0 * m if fused else 9.0 * n + 3.0 * m,
@@ -78,7 +87,8 @@ def algorithmic_bytes(geo, fused: bool = None) -> dict:
 
 
 # bench kernel family -> prefix of the rocprofv3 kernel name(s) (template arguments change between builds: matched by prefix)
-ROCPROF_PREFIXES = {"tile_extract": ["k_tile_extract"], "down_l0": ["k_down_march<0,"], "down_l1p": ["k_down_march<2,"],
+ROCPROF_PREFIXES = {"tile_extract": ["k_tile_extract"], "down_l0": ["k_down_march<0,", "k_down2_march<"],
+                    "down_l1p": ["k_down_march<2,", "k_down2_cols"],
                     "up_level": ["k_up_level_blk<"],
                     "final_gather": ["k_final_fast<", "k_final_fused<", "k_final_march1<", "k_final_marchn<"],
                     "assess_all": ["k_assess_march<"]}

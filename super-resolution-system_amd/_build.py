@@ -19,7 +19,7 @@ LIB = os.path.join(_HERE, "libsrhip.so")
 OBJ_DIR = os.path.join(_HERE, "build")
 SOURCES = [os.path.join(CSRC, n) for n in ("sr_engine.hip", "sr_lpips.hip", "sr_adjust.hip", "sr_encode.cpp",
                                            "sr_comm.cpp", "sr_host.cpp")]
-HEADERS = [os.path.join(CSRC, "sr_internal.h"), os.path.join(CSRC, "sr_ctx.h"), os.path.join(CSRC, "sr_march.inc"),
+HEADERS = [os.path.join(CSRC, "sr_internal.h"), os.path.join(CSRC, "sr_ctx.h"), os.path.join(CSRC, "sr_march.inc"), os.path.join(CSRC, "sr_down2.inc"),
            os.path.join(_ROOT, "include", "sr_hip.h")]
 
 

@@ -8,7 +8,7 @@
 //   * external images / tiles / canvas: row-major HWC, u8 (or fp32 tiles), byte strides --
 //     exactly the reference's ndarrays.
 //   * internal pyramid levels i >= 1 of every tile live in one arena: planar fp32, plane
-//     c of level i at  off[i] + c * H_i * P_i,  row pitch P_i = round_up(W_i, 16) floats.
+//     c of level i at  off[i] + c * H_i * P_i,  row pitch P_i = round_up(W_i, 32) floats (whole 128-byte lines).
 //     G_i = Gaussian level, R_i = collapsed weighted-Laplacian level, W_i = weight level
 //     (one per distinct tile shape).
 //   * the fp32 canvas accumulators of the reference are never materialised: the final kernel
@@ -226,6 +226,7 @@ typedef float f4_t __attribute__((ext_vector_type(4)));
 typedef float f2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u3_t __attribute__((ext_vector_type(3)));
+typedef unsigned u2_t __attribute__((ext_vector_type(2)));
 typedef f4_t f4_a4_t __attribute__((aligned(4)));    // 4 floats at any float-aligned address
 typedef f2_t f2_a8_t __attribute__((aligned(8)));
 typedef u3_t u3_a1_t __attribute__((aligned(1)));    // 12 bytes at any address
@@ -332,6 +333,9 @@ __host__ __device__ __forceinline__ int down_ncg(int ws, int wo)
     return a < b ? a : b;
 }
 
+struct TileDev;
+__host__ __device__ __forceinline__ bool down2_takes(const TileDev &T);     // sr_down2.inc
+
 // REFLECT_101 of a row index that leaves [0, n) by at most n - 1 (one bounce, no loop) -- the march's rows do by <= 2
 __device__ __forceinline__ int reflect101_once(int p, int n)
 {
@@ -398,10 +402,11 @@ __device__ __forceinline__ void down_row_f32(const float (&s)[11], float (&h)[4]
 template <int SRC, int CN>
 __global__ __launch_bounds__(256) void k_down_march(const TileDev *__restrict__ tiles, const TileSrc *__restrict__ srcs,
                                                     int lvl, int seg_rows, int march_blocks, float *__restrict__ arena,
-                                                    const float *__restrict__ luts)
+                                                    const float *__restrict__ luts, int skip_down2)
 {
     const TileDev &T = tiles[blockIdx.z];
     if (lvl + 1 >= T.nl) return;
+    if (skip_down2 && down2_takes(T)) return;                       // levels 1 and 2 of this tile come from k_down2_march
     const int ws = T.W[lvl], hs = T.H[lvl], wo = T.W[lvl + 1];
     const int ya = T.g0[lvl + 1], yb = T.g1[lvl + 1];
     const int ncg = down_ncg(ws, wo);
@@ -1779,6 +1784,7 @@ __global__ __launch_bounds__(FU_THREADS, FU_WAVES) void k_final_fused(const Fina
 }
 
 #include "sr_march.inc"
+#include "sr_down2.inc"
 
 // ---------------------------------------------------------------------------------------------
 // dense HWC pyramid primitives (API utilities for build_gaussian_pyramid & friends)
@@ -3047,6 +3053,7 @@ struct sr_blend_plan {
     int n_fedge_blocks = 0;
     // marched zones (k_final_march): work items per tile count, and the regular blocks of k_final_fused that remain
     bool march = false;
+    bool down2 = true;               // levels 1 and 2 of full-window u8 RGB tiles in one march (sr_down2.inc); SR_DOWN2=0: two launches
     MarchItem *d_march_items[MARCH_NT + 1] = {nullptr};
     int n_march_items[MARCH_NT + 1] = {0};
     long long n_march_total = 0;
@@ -3635,6 +3642,8 @@ int sr_blend_plan_create(sr_ctx *ctx, const sr_tile_rect *h_tiles, int n, int cn
         P->fused = (cn == 3 || cn == 1) && !(env && env[0] == '0');     // SR_FUSED_FINAL=0: the unfused pair (A/B runs)
         const char *env2 = std::getenv("SR_MARCH");
         P->march = P->fused && !(env2 && env2[0] == '0');               // SR_MARCH=0: every zone through k_final_fused (A/B runs)
+        const char *env3 = std::getenv("SR_DOWN2");
+        P->down2 = !(env3 && env3[0] == '0');
     }
 
     std::map<std::pair<int, int>, int> cls_of;
@@ -3684,7 +3693,7 @@ int sr_blend_plan_create(sr_ctx *ctx, const sr_tile_rect *h_tiles, int n, int cn
             for (int i = 0; i < T.nl; ++i) {
                 C.H[i] = lv[t].H[i];
                 C.W[i] = lv[t].W[i];
-                C.P[i] = round_up(C.W[i], 16);
+                C.P[i] = round_up(C.W[i], 32);
                 C.g0[i] = C.g1[i] = 0;
                 if (i >= 1) {
                     C.g_off[i] = (long long)off;
@@ -3701,7 +3710,7 @@ int sr_blend_plan_create(sr_ctx *ctx, const sr_tile_rect *h_tiles, int n, int cn
         for (int i = 0; i < T.nl; ++i) {
             T.H[i] = lv[t].H[i];
             T.W[i] = lv[t].W[i];
-            T.P[i] = round_up(T.W[i], 16);
+            T.P[i] = round_up(T.W[i], 32);
             T.g0[i] = lv[t].gw[i].a;
             T.g1[i] = lv[t].gw[i].b;
             T.r0[i] = lv[t].rw[i].a;
@@ -4090,11 +4099,63 @@ static int blend_pyramids(sr_blend_plan *P, int dtype, void *const *h_d_tiles, c
         d_tiles = (const TileDev *)slot->d;
         d_srcs = (const TileSrc *)((const char *)slot->d + o_src);
     }
+    // tiles whose levels 1 and 2 come out of one march (u8 RGB, 32-bit offsets inside a tile and the arena)
+    int n_take = 0, max_take_h1 = 0, max_take_h2 = 0;
+    if (P->down2 && P->cn == 3 && dtype == SR_U8 && P->arena_floats * sizeof(float) < 0xFFFF0000ull) {
+        bool ok = true;
+        for (int k = 0; k < n_idx && ok; ++k)
+            ok = sub_s[k].stride > 0 && (unsigned long long)sub_s[k].stride * (unsigned long long)(P->tiles[idx[k]].H[0] + 2) < 0x7FFF0000ull;
+        for (int k = 0; k < n_idx && ok; ++k) {
+            const TileDev &T = P->tiles[idx[k]];
+            if (!down2_takes(T)) continue;
+            ++n_take;
+            max_take_h1 = std::max(max_take_h1, T.H[1]);
+            max_take_h2 = std::max(max_take_h2, T.H[2]);
+        }
+    }
     // Gaussian chain
     for (int i = 0; i + 1 < max_nl; ++i) {
         if (max_g[i + 1] <= 0) continue;
         ProfScope ps(ctx, i == 0 ? "down_l0" : "down_l1p");
         const bool blk = (P->cn == 3 || P->cn == 1) && !(i == 0 && dtype != SR_U8);
+        int skip2 = 0;
+        if (blk && i <= 1 && n_take > 0) {
+            // levels 1 and 2 of the tiles with full row windows in one march (sr_down2.inc); the others keep the two launches
+            if (i == 0) {
+                // Segment length (level-2 rows per work item).  Every item pays three extra level-1 rows, yet short segments win:
+                // measured at 200 MP (tools/down2_seg_sweep.sh) 6 .. 12 rows 0.51-0.54 ms, 16: 0.58, 32: 0.61, 64: 0.68 -- the
+                // kernel is bound by its stores' way through the memory system, which many short items keep busier.  The longest
+                // length up to 12 that still gives every wave slot four items, never below 6.
+                int items = 0, seg2 = 12;
+                {
+                    const long long slots = (long long)ctx->num_cu * 16;    // four waves per SIMD
+                    const char *envs = std::getenv("SR_DOWN2_SEG");     // timing runs: a fixed segment length
+                    const int hi = envs ? std::max(2, atoi(envs)) : 12, lo = envs ? hi : 6;
+                    for (int cand = hi; cand >= lo; --cand) {
+                        long long total = 0;
+                        items = 0;
+                        seg2 = cand;
+                        for (int k = 0; k < n_idx; ++k) {
+                            const TileDev &T = P->tiles[idx[k]];
+                            if (!down2_takes(T)) continue;
+                            const int it = down2_nstrip(down_ncg(T.W[0], T.W[1])) * ((T.H[2] + cand - 1) / cand);
+                            items = std::max(items, it);
+                            total += it;
+                        }
+                        if (total >= 4 * slots) break;
+                    }
+                }
+                const bool probe_nb = std::getenv("SR_DOWN2_PROBE_NOBORDER") != nullptr;     // timing probe only (wrong border columns)
+                dim3 grid2(items + (probe_nb ? 0 : (max_take_h1 + 3) / 4), 1, n_idx);
+                hipLaunchKernelGGL((k_down2_march<3>), grid2, dim3(64), 0, ctx->stream, d_tiles, d_srcs, seg2, items, P->d_arena,
+                                   (unsigned)(P->arena_floats * sizeof(float)), P->d_arena, P->d_luts);
+            } else {
+                dim3 grid2((max_take_h2 + 15) / 16, 1, n_idx);
+                hipLaunchKernelGGL(k_down2_cols, grid2, dim3(256), 0, ctx->stream, d_tiles, P->cn, P->d_arena, P->d_luts);
+            }
+            if (n_take == n_idx) continue;
+            skip2 = 1;
+        }
         if (blk) {
             int max_cells = 0, seg_rows = 2;
             for (int cand = 32; cand >= 2; cand /= 2) {       // longest segments that still give ~8 blocks per CU;
@@ -4116,11 +4177,11 @@ static int blend_pyramids(sr_blend_plan *P, int dtype, void *const *h_d_tiles, c
                 const int march_blocks = (max_cells + 255) / 256, cols_blocks = (max_g[i + 1] + 15) / 16;
                 dim3 grid(march_blocks + cols_blocks, 1, n_idx);
                 if (i == 0) {
-                    if (P->cn == 3) hipLaunchKernelGGL((k_down_march<SRC_U8, 3>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, seg_rows, march_blocks, P->d_arena, P->d_luts);
-                    else hipLaunchKernelGGL((k_down_march<SRC_U8, 1>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, seg_rows, march_blocks, P->d_arena, P->d_luts);
+                    if (P->cn == 3) hipLaunchKernelGGL((k_down_march<SRC_U8, 3>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, seg_rows, march_blocks, P->d_arena, P->d_luts, skip2);
+                    else hipLaunchKernelGGL((k_down_march<SRC_U8, 1>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, seg_rows, march_blocks, P->d_arena, P->d_luts, skip2);
                 } else {
-                    if (P->cn == 3) hipLaunchKernelGGL((k_down_march<SRC_PLANAR, 3>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, seg_rows, march_blocks, P->d_arena, P->d_luts);
-                    else hipLaunchKernelGGL((k_down_march<SRC_PLANAR, 1>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, seg_rows, march_blocks, P->d_arena, P->d_luts);
+                    if (P->cn == 3) hipLaunchKernelGGL((k_down_march<SRC_PLANAR, 3>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, seg_rows, march_blocks, P->d_arena, P->d_luts, skip2);
+                    else hipLaunchKernelGGL((k_down_march<SRC_PLANAR, 1>), grid, block, 0, ctx->stream, d_tiles, d_srcs, i, seg_rows, march_blocks, P->d_arena, P->d_luts, skip2);
                 }
             }
             continue;
