@@ -248,7 +248,7 @@ __device__ __forceinline__ u3_t ld_u3_a1_g(const void *p)
 // One output pixel (all planes) of level lvl+1 from level lvl -- the generic form with every border rule.
 template <int SRC>
 __device__ __forceinline__ void down_pixel(const TileDev &T, const TileSrc S, int lvl, int cn, int x, int y,
-                                           float *__restrict__ arena, const float *__restrict__ luts)
+                                           float *__restrict__ arena, const float *__restrict__ luts, int c_only = -1)
 {
     const int hs = T.H[lvl], ws = T.W[lvl];
     int xi[5], yi[5];
@@ -260,7 +260,8 @@ __device__ __forceinline__ void down_pixel(const TileDev &T, const TileSrc S, in
     const int po = T.P[lvl + 1];
     float *dst = arena + T.g_off[lvl + 1] + (size_t)y * po + x;
     const size_t dplane = (size_t)T.H[lvl + 1] * po;
-    for (int c = 0; c < cn; ++c) {
+    // c_only >= 0: that plane alone (a thread per plane: its 25 loads are one round trip, no store of another plane between them)
+    for (int c = c_only >= 0 ? c_only : 0; c < (c_only >= 0 ? c_only + 1 : cn); ++c) {
         float rowv[5];
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
@@ -4100,7 +4101,7 @@ static int blend_pyramids(sr_blend_plan *P, int dtype, void *const *h_d_tiles, c
         d_srcs = (const TileSrc *)((const char *)slot->d + o_src);
     }
     // tiles whose levels 1 and 2 come out of one march (u8 RGB, 32-bit offsets inside a tile and the arena)
-    int n_take = 0, max_take_h1 = 0, max_take_h2 = 0;
+    int n_take = 0, max_take_h1 = 0, max_take_cols = 0;
     if (P->down2 && P->cn == 3 && dtype == SR_U8 && P->arena_floats * sizeof(float) < 0xFFFF0000ull) {
         bool ok = true;
         for (int k = 0; k < n_idx && ok; ++k)
@@ -4110,7 +4111,7 @@ static int blend_pyramids(sr_blend_plan *P, int dtype, void *const *h_d_tiles, c
             if (!down2_takes(T)) continue;
             ++n_take;
             max_take_h1 = std::max(max_take_h1, T.H[1]);
-            max_take_h2 = std::max(max_take_h2, T.H[2]);
+            max_take_cols = std::max(max_take_cols, T.H[2] * down2_cols_count(T));
         }
     }
     // Gaussian chain
@@ -4150,8 +4151,8 @@ static int blend_pyramids(sr_blend_plan *P, int dtype, void *const *h_d_tiles, c
                 hipLaunchKernelGGL((k_down2_march<3>), grid2, dim3(64), 0, ctx->stream, d_tiles, d_srcs, seg2, items, P->d_arena,
                                    (unsigned)(P->arena_floats * sizeof(float)), P->d_arena, P->d_luts);
             } else {
-                dim3 grid2((max_take_h2 + 15) / 16, 1, n_idx);
-                hipLaunchKernelGGL(k_down2_cols, grid2, dim3(256), 0, ctx->stream, d_tiles, P->cn, P->d_arena, P->d_luts);
+                dim3 grid2((max_take_cols + 255) / 256, 1, n_idx);
+                hipLaunchKernelGGL(k_down2_cols, grid2, dim3(256), 0, ctx->stream, d_tiles, P->d_arena);
             }
             if (n_take == n_idx) continue;
             skip2 = 1;

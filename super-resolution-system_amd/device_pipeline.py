@@ -304,9 +304,12 @@ class DevicePipeline:
         self.canvases = [torch.zeros((geo.canvas_h, geo.canvas_w * cn), **u8) for _ in range(2)]
         self.results_bufs = [torch.zeros(4, dtype=torch.float64, device=self.dev) for _ in range(2)]   # sr_assess_sums
         self.main_stream = torch.cuda.current_stream(self.dev)
-        self.qa_stream = torch.cuda.Stream(self.dev)
-        self.qa_ctx = _native.Context(self.device, stream=self.qa_stream.cuda_stream)
         import os as _os
+        # SR_QA_STREAM_PRIO (experiments): HIP priority of the assessment's stream (lower number = served first; the chain
+        # runs on the caller's stream at the default priority 0)
+        _prio = _os.environ.get("SR_QA_STREAM_PRIO")
+        self.qa_stream = torch.cuda.Stream(self.dev, priority=int(_prio)) if _prio else torch.cuda.Stream(self.dev)
+        self.qa_ctx = _native.Context(self.device, stream=self.qa_stream.cuda_stream)
         self._assess_split = _os.environ.get("SR_ASSESS_SPLIT", "0") == "1"
         self._qa_gate = _os.environ.get("SR_QA_GATE", "0") == "1"
         self._gated = None

@@ -9,7 +9,7 @@ for d in variants/*/; do
   name=$(basename $d)
   cp $d/libsrhip.so $PK/libsrhip.so; cp $d/libsrhip.digest $PK/libsrhip.digest
   env SR_HIPCC_EXTRA="$(cat $d/flags)" "$@" timeout -k 10 200 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pcie --sweep none 2>/dev/null | tail -1 |
-    python3 -c "import json,sys; d=json.loads(sys.stdin.read()); k=d['kernels']; print('$name', {a:round(b['ms_per_step'],4) for a,b in k.items()}, 'blend', d['roofline_blend']['ms'], 'step', d['ms_per_step'])" >> $OUT || { echo "$name failed" >> $OUT; break; }
+    python3 tools/bench_line.py $name >> $OUT || { echo "$name failed" >> $OUT; break; }
 done
 cp /tmp/libsrhip.keep $PK/libsrhip.so; cp /tmp/libsrhip.digest.keep $PK/libsrhip.digest
 cat $OUT
