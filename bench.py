@@ -90,7 +90,7 @@ def algorithmic_bytes(geo, fused: bool = None) -> dict:
 ROCPROF_PREFIXES = {"tile_extract": ["k_tile_extract"], "down_l0": ["k_down_march<0,", "k_down2_march<"],
                     "down_l1p": ["k_down_march<2,", "k_down2_cols"],
                     "up_level": ["k_up_level_blk<"],
-                    "final_gather": ["k_final_fast<", "k_final_fused<", "k_final_march1<", "k_final_marchn<"],
+                    "final_gather": ["k_final_fast<", "k_final_fused<", "k_final_march1<", "k_final_marchn<", "k_final_marchp<"],
                     "assess_all": ["k_assess_march<"]}
 BLEND_FAMILIES = ("down_l0", "down_l1p", "up_level", "final_gather")
 # VALU model of the fused assessment: per pixel (= per thread and row) the march issues ~223 VALU instructions

@@ -4277,14 +4277,24 @@ static int blend_gather(sr_blend_plan *P, bool lap, int dtype, void *const *h_d_
     hipLaunchKernelGGL((k_final_marchn<CNV, NTV>), dim3((unsigned)P->n_march_items[NTV]), dim3(64 * NTV), 0, ms[NTV == 2 ? 0 : 1],  \
                        P->d_march_items[NTV], P->d_fdesc, P->d_arena, arena_bytes, P->d_luts, d_canvas,                      \
                        (long long)canvas_stride, d_canvas_f32, P->canvas_w)
+#define LAUNCH_MARCHP(NTV)                                                                                               \
+    hipLaunchKernelGGL((k_final_marchp<NTV>), dim3((unsigned)P->n_march_items[NTV]), dim3(192 * NTV), 0, ms[NTV == 2 ? 0 : 1],  \
+                       P->d_march_items[NTV], P->d_fdesc, P->d_arena, arena_bytes, P->d_luts, d_canvas,                      \
+                       (long long)canvas_stride, d_canvas_f32, P->canvas_w)
             static_assert(MARCH_NT == 4, "the tile counts launched here");
             for (int nt = 2; nt <= MARCH_NT && dtype == SR_U8; ++nt) {
                 if (P->n_march_items[nt] <= 0) continue;
                 ProfScope ps2(ctx, nt == 2 ? "gather_march2" : (nt == 3 ? "gather_march3" : "gather_march4"));
-                if (P->cn == 3) { if (nt == 2) LAUNCH_MARCHN(3, 2); else if (nt == 3) LAUNCH_MARCHN(3, 3); else LAUNCH_MARCHN(3, 4); }
+                // SR_MARCH_PLANES=1 (A/B runs): a wave per (tile, plane) (k_final_marchp) instead of a wave per tile with all planes.
+                // Measured and rejected: two tiles 0.42 -> 0.59 ms, four 0.165 -> 0.216 -- the step waits on its requests, and
+                // three waves that each fetch the shared pixels and W_1 issue 30 requests per strip and step where two issued 18.
+                static const bool planes = std::getenv("SR_MARCH_PLANES") && std::getenv("SR_MARCH_PLANES")[0] == '1';
+                if (P->cn == 3 && planes) { if (nt == 2) LAUNCH_MARCHP(2); else if (nt == 3) LAUNCH_MARCHP(3); else LAUNCH_MARCHP(4); }
+                else if (P->cn == 3) { if (nt == 2) LAUNCH_MARCHN(3, 2); else if (nt == 3) LAUNCH_MARCHN(3, 3); else LAUNCH_MARCHN(3, 4); }
                 else            { if (nt == 2) LAUNCH_MARCHN(1, 2); else if (nt == 3) LAUNCH_MARCHN(1, 3); else LAUNCH_MARCHN(1, 4); }
             }
 #undef LAUNCH_MARCHN
+#undef LAUNCH_MARCHP
             const long long n_reg = marched ? P->n_freg : P->n_freg_all;
             const int *reg_list = marched ? P->d_freg_list : P->d_freg_all;
             ProfScope ps3(ctx, "gather_rest");
