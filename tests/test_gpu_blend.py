@@ -231,3 +231,29 @@ def test_plan_reuse_with_changing_tile_buffers(ctx, rng):
         ctx.tile_extract(d_img.ptr, 90, 140, 3, 140 * 3, xywh, [o.ptr for o in outs], [w * 3 for (_, _, w, _) in xywh])
         for (x, y, w, h), o in zip(xywh, outs):
             assert np.array_equal(ctx.download(o.ptr, (h, w, 3), np.uint8), img[y:y + h, x:x + w])
+
+
+# Shapes chosen against k_down2_march (csrc/sr_down2.inc): 1, 2, 3 and many column groups; widths that leave 0 .. 7 border
+# columns on the right; level-1 heights odd and even (the two closing formulas of level 2); heights around the segment length;
+# row strides of every alignment (the dword shift of a row's window changes from row to row when 3 w is not a multiple of 4).
+DOWN2_SHAPES = [(33, 18), (40, 26), (41, 27), (50, 34), (51, 35), (64, 42), (97, 43), (98, 50), (99, 51), (131, 66), (200, 203),
+                (201, 404), (67, 805), (405, 90), (406, 91), (407, 92), (408, 93)]
+
+
+@pytest.mark.parametrize("h,w", DOWN2_SHAPES)
+def test_down2_march_shapes(ctx, rng, h, w, monkeypatch):
+    """Levels 1 and 2 from one march (default) against the oracle AND against the two launches of round 3 (SR_DOWN2=0):
+    fp32 canvas bit-exact, u8 canvas identical; two overlapping tiles so that every level of both is used."""
+    tiles = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8), rng.integers(0, 256, (h, w, 3), dtype=np.uint8)]
+    tiles[1][: h // 2] = 255                       # saturated and zero areas: the 16-bit row and column sums at their maxima
+    tiles[0][h // 2:, : w // 3] = 0
+    ov = max(w // 3, 4)
+    pos = [(0, 0), (3, w - ov)]
+    shape = (h + 3, 2 * w - ov)
+    ref_u8, ref_f = oc.laplacian_fusion(tiles, pos, shape, 6, "cosine", return_float=True)
+    out_u8, out_f = ctx.fusion_np(tiles, pos, shape, 6, "cosine", laplacian=True, return_float=True)
+    assert np.array_equal(out_f, ref_f), float(np.nanmax(np.abs(out_f - ref_f)))
+    assert np.array_equal(out_u8, ref_u8)
+    monkeypatch.setenv("SR_DOWN2", "0")            # read when the plan is made
+    old_u8, old_f = ctx.fusion_np(tiles, pos, shape, 6, "cosine", laplacian=True, return_float=True)
+    assert np.array_equal(old_f, out_f) and np.array_equal(old_u8, out_u8)
