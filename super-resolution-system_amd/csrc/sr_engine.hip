@@ -4100,7 +4100,8 @@ static int blend_pyramids(sr_blend_plan *P, int dtype, void *const *h_d_tiles, c
         d_tiles = (const TileDev *)slot->d;
         d_srcs = (const TileSrc *)((const char *)slot->d + o_src);
     }
-    // tiles whose levels 1 and 2 come out of one march (u8 RGB, 32-bit offsets inside a tile and the arena)
+    // tiles whose levels 1 and 2 come out of one march (u8 RGB, 32-bit offsets inside a tile and the arena; a strip's row
+    // windows included)
     int n_take = 0, max_take_h1 = 0, max_take_cols = 0;
     if (P->down2 && P->cn == 3 && dtype == SR_U8 && P->arena_floats * sizeof(float) < 0xFFFF0000ull) {
         bool ok = true;
@@ -4110,8 +4111,8 @@ static int blend_pyramids(sr_blend_plan *P, int dtype, void *const *h_d_tiles, c
             const TileDev &T = P->tiles[idx[k]];
             if (!down2_takes(T)) continue;
             ++n_take;
-            max_take_h1 = std::max(max_take_h1, T.H[1]);
-            max_take_cols = std::max(max_take_cols, T.H[2] * down2_cols_count(T));
+            max_take_h1 = std::max(max_take_h1, T.g1[1] - T.g0[1]);
+            max_take_cols = std::max(max_take_cols, (T.g1[2] - T.g0[2]) * down2_cols_count(T));
         }
     }
     // Gaussian chain
@@ -4139,7 +4140,7 @@ static int blend_pyramids(sr_blend_plan *P, int dtype, void *const *h_d_tiles, c
                         for (int k = 0; k < n_idx; ++k) {
                             const TileDev &T = P->tiles[idx[k]];
                             if (!down2_takes(T)) continue;
-                            const int it = down2_nstrip(down_ncg(T.W[0], T.W[1])) * ((T.H[2] + cand - 1) / cand);
+                            const int it = down2_nstrip(down_ncg(T.W[0], T.W[1])) * ((T.g1[2] - T.g0[2] + cand - 1) / cand);
                             items = std::max(items, it);
                             total += it;
                         }
