@@ -3092,7 +3092,15 @@ static void plan_march(const sr_blend_plan *P, int nbx_r, int nby_r, std::vector
     // the marched kernels address the arena and a tile's pixels with 32-bit byte offsets (buffer instructions)
     bool fits32 = P->arena_floats * sizeof(float) < 0xFFFF0000ull && (unsigned long long)cw * P->cn * 4ull * (2 * MARCH_SEG + 2) < 0xFFFF0000ull;
     for (int t = 0; t < n && fits32; ++t) fits32 = (unsigned long long)P->tiles[t].h * P->tiles[t].w * P->cn * 4ull < 0x7FFF0000ull;
-    const bool on = P->march && fits32 && n <= 128 && ncx >= 3 && ncy >= 2;
+    // The march is four launches of long work items: it wins on a big canvas (200 MP: 1.12 against 1.22 ms for the block kernel
+    // alone) and loses on a small one, where every launch is a few short items deep -- a rank's strip of a world of 4 / 8:
+    // 0.39 / 0.27 ms against 0.33 / 0.18 (tools/virtual_scaling.py, profiles/r04_virtual_scaling.json); even at 100 MP.
+    // SR_MARCH=2 marches whatever the size, SR_MARCH_MIN_MP moves the threshold (A/B runs).
+    const char *env_force = std::getenv("SR_MARCH");               // read per plan: the tests switch it
+    const char *env_min = std::getenv("SR_MARCH_MIN_MP");
+    const double min_px = (env_min ? atof(env_min) : 90.0) * 1e6;
+    const bool big = (env_force && env_force[0] == '2') || (double)rows * (double)cw >= min_px;
+    const bool on = P->march && big && fits32 && n <= 128 && ncx >= 3 && ncy >= 2;
     if (on) {
         auto xclass = [&](const TileDev &T, int x0) -> unsigned char {
             const long long lx0 = (long long)x0 - T.x;

@@ -12,6 +12,12 @@ for p in (ROOT, PKG):
         sys.path.insert(0, p)
 
 
+# The marched gather (csrc/sr_march.inc) is taken from 90 MP of canvas up (below that its four launches lose to the block
+# kernel alone); the suite's small canvases march all the same, so that both forms of the gather stay under test -- tests that
+# compare the two switch SR_MARCH themselves (it is read when a plan is made).
+os.environ.setdefault("SR_MARCH", "2")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

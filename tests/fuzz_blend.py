@@ -21,6 +21,8 @@ def run(cases: int = 200, seed: int = 1) -> int:
     bad = 0
     compared = rejected = strips = 0
     for it in range(cases):
+        # both forms of the canvas gather: the march (forced: the default takes it from 90 MP of canvas up) and the block kernel
+        os.environ["SR_MARCH"] = "2" if it % 3 else "1"
         n = int(rng.integers(1, 7))
         cn = int(rng.choice([1, 3]))
         levels = int(rng.integers(1, 7))

@@ -52,8 +52,10 @@ GRIDS = [
 ]
 
 
+@pytest.mark.parametrize("march", ["2", "1"])          # the marched gather forced / the default of a small canvas: the block kernel
 @pytest.mark.parametrize("th,tw,rows,cols,ov,levels,wt", GRIDS)
-def test_laplacian_fusion_grid(ctx, rng, th, tw, rows, cols, ov, levels, wt):
+def test_laplacian_fusion_grid(ctx, rng, th, tw, rows, cols, ov, levels, wt, march, monkeypatch):
+    monkeypatch.setenv("SR_MARCH", march)
     tiles = _tiles(rng, rows * cols, th, tw)
     pos = [((i // cols) * (th - ov), (i % cols) * (tw - ov)) for i in range(rows * cols)]
     shape = (rows * th - (rows - 1) * ov, cols * tw - (cols - 1) * ov)
