@@ -26,20 +26,38 @@ tw, th = geo.rects[0][2], geo.rects[0][3]
 tiles = torch.randint(0, 256, (len(geo.rects), th, tw * cn), dtype=torch.uint8, device=dev, generator=g)
 
 
-def run():
+# a `mean_std` table (blending_module._mean_std_table): float values, not integers -- the fused kernels' exact integer sums do not apply
+lut_f = np.clip((lut - 120.0) * np.float32(1.07) + np.float32(131.3), 0, 255).astype(np.float32)
+EPS = 0.01                    # the reference's eps (blending_module.py:1092-1146)
+
+
+def run(table):
     ctx.histogram_u8(img.data_ptr(), W * cn, H, W, cn)
-    ctx.color_correct_u8(img.data_ptr(), W * cn, H, W, cn, lut, False, 8, 1e-3, out.data_ptr(), W * cn)
-    ctx.color_correct_u8(img.data_ptr(), W * cn, H, W, cn, lut, 1, 8, 1e-3, out.data_ptr(), W * cn)      # _simple_guided_filter
-    ctx.color_correct_u8(img.data_ptr(), W * cn, H, W, cn, lut, 2, 8, 1e-3, out.data_ptr(), W * cn)      # the ximgproc branch
+    ctx.color_correct_u8(img.data_ptr(), W * cn, H, W, cn, table, False, 8, EPS, out.data_ptr(), W * cn)
+    ctx.color_correct_u8(img.data_ptr(), W * cn, H, W, cn, table, 1, 8, EPS, out.data_ptr(), W * cn)      # _simple_guided_filter
+    ctx.color_correct_u8(img.data_ptr(), W * cn, H, W, cn, table, 2, 8, EPS, out.data_ptr(), W * cn)      # the ximgproc branch
     ctx.gray_std_u8(tiles.data_ptr(), len(geo.rects), th * tw * cn, tw * cn, th, tw)
 
 
-run()
-torch.cuda.synchronize()
-ctx.prof_enable(True)
-ctx.prof_reset()
-run()
-torch.cuda.synchronize()
-print(json.dumps({"image": f"{W}x{H}", "tiles": f"{len(geo.rects)} x {tw}x{th}",
-                  "kernel_ms": {k: round(ms, 3) for k, (ms, n) in ctx.prof_get().items()},
+def timed(table):
+    run(table)
+    torch.cuda.synchronize()
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    e0, e1, e2, e3 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+    e0.record()
+    ctx.color_correct_u8(img.data_ptr(), W * cn, H, W, cn, table, 1, 8, EPS, out.data_ptr(), W * cn)
+    e1.record()
+    ctx.color_correct_u8(img.data_ptr(), W * cn, H, W, cn, table, 2, 8, EPS, out.data_ptr(), W * cn)
+    e2.record()
+    run(table)
+    torch.cuda.synchronize()
+    k = {k: round(ms, 3) for k, (ms, n) in ctx.prof_get().items()}
+    ctx.prof_enable(False)
+    return {"kernel_ms_two_calls_each": k, "call_ms": {"simple": round(e0.elapsed_time(e1), 3), "ximgproc": round(e1.elapsed_time(e2), 3)}}
+
+
+res_int, res_float = timed(lut), timed(lut_f)
+print(json.dumps({"image": f"{W}x{H}", "tiles": f"{len(geo.rects)} x {tw}x{th}", "eps": EPS,
+                  "integer_table": res_int, "float_table": res_float,
                   "bytes_GB": {"histogram": round(H * W * cn / 1e9, 3), "lut_apply": round(2 * H * W * cn / 1e9, 3)}}))
