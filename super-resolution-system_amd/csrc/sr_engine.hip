@@ -1307,6 +1307,10 @@ __global__ __launch_bounds__(256, SR_FINAL_WAVES) void k_final_fast(const FinalD
 #define FU_E1W 16                           /* edge shape 1: FU_E1W x FU_E1H pixels (4 cells across: a vertical tile edge
                                                makes 1 - 3 of them border cells) */
 #define FU_E1H (FU_THREADS / 2)
+#ifndef FU_DB
+#define FU_DB 0                /* 1: two LDS windows per block taken in turn (one barrier per tile instead of two): measured
+                                  and rejected, 0.21 -> 0.26 ms for the 200 MP grid's remainder -- three blocks per CU instead of four */
+#endif
 #define FU_LP 72              /* LDS pitch (floats) of a regular block's window: 18 patches of 4 columns */
 /* pixels per plane window (two floats each): rows = block rows / 2 + 3, rounded up to even; 72 (regular), 136 (shape 0) or
    24 (shape 1) columns */
@@ -1627,8 +1631,10 @@ __device__ __forceinline__ void fused_edge_block(const FinalDesc *__restrict__ d
 #pragma unroll
             for (int c = 0; c < CN; ++c) acc[j][k][c] = 0.f;
         }
+    float *const lds_all = lds;
     for (int i = c_begin; i < c_end; ++i) {
         const FinalDesc &D = descs[cand_idx[i]];
+        if (FU_DB) lds = lds_all + ((i - c_begin) & 1) * (2 * CN * FU_PLANE);
         int R0 = 0, C0 = 0, npr = 0, npc = 0;
         const bool win = D.nl > 1 && fused_window(D, eb.x - D.x, eb.y - D.y, bw, bh, R0, C0, npr, npc);
         if (win) fused_stage1<CN>(D, arena, lds, R0, C0, npr, npc, LP, tid);
@@ -1675,7 +1681,7 @@ __device__ __forceinline__ void fused_edge_block(const FinalDesc *__restrict__ d
             else if (!xo && yo) fused_gather_generic<DT, CN, false, true>(D, luts, lds, LP, R0, C0, lx0, ly0, valid, acc, wacc);
             else fused_gather_generic<DT, CN, true, true>(D, luts, lds, LP, R0, C0, lx0, ly0, valid, acc, wacc);
         }
-        __syncthreads();                                   // the next tile's stage 1 overwrites the window
+        if (!FU_DB) __syncthreads();                       // the next tile's stage 1 overwrites the window
     }
     if (edge) store_pixels<CN>(acc, wacc, canvas, cstride, canvas_f32, cw, x0, y0, nx, ny);
 }
@@ -1689,7 +1695,10 @@ __global__ __launch_bounds__(FU_THREADS, FU_WAVES) void k_final_fused(const Fina
                                                         unsigned char *__restrict__ canvas, long long cstride,
                                                         float *__restrict__ canvas_f32, int cw, int row_begin, int row_end)
 {
-    __shared__ __attribute__((aligned(16))) float lds[2 * CN * FU_PLANE];
+    // FU_DB: two windows, taken in turn by the tiles of a block -- the barrier that kept a tile's stage 1 from overwriting the window
+    // the previous tile's gather still reads is not needed then (one barrier per tile instead of two, 52 instead of 26 KB of LDS)
+    __shared__ __attribute__((aligned(16))) float lds_all[(FU_DB ? 2 : 1) * 2 * CN * FU_PLANE];
+    float *lds = lds_all;
     if ((int)blockIdx.x < n_edge) {
         fused_edge_block<DT, CN>(descs, edge_blocks, (int)blockIdx.x, edge_cand, arena, luts, lds, canvas, cstride, canvas_f32, cw,
                                  row_begin, row_end);
@@ -1751,6 +1760,7 @@ __global__ __launch_bounds__(FU_THREADS, FU_WAVES) void k_final_fused(const Fina
         }
     for (int i = c_begin; i < c_end; ++i) {
         const FinalDesc &D = descs[cand_idx[i]];
+        if (FU_DB) lds = lds_all + ((i - c_begin) & 1) * (2 * CN * FU_PLANE);
         const int lxa = sbx - D.x, lya = sby - D.y;
         int R0 = 0, C0 = 0, npr = 0, npc = 0;
         const bool win = D.nl > 1 && fused_window(D, lxa, lya, sbw, sbh, R0, C0, npr, npc);        // block-uniform
@@ -1779,7 +1789,7 @@ __global__ __launch_bounds__(FU_THREADS, FU_WAVES) void k_final_fused(const Fina
             }
 #undef FU_CALL
         }
-        __syncthreads();                                       // the next tile's stage 1 overwrites the window
+        if (!FU_DB) __syncthreads();                           // the next tile's stage 1 overwrites the window
     }
     if (alive) store_pixels<CN>(acc, wacc, canvas, cstride, canvas_f32, cw, x0, y0, nx, ny);   // ragged cells without a visit: zeros
 }
