@@ -395,8 +395,14 @@ SR_API int sr_resize_cubic_window_u8(sr_ctx *ctx, const uint8_t *d_src, int64_t 
  * local_filter == 2 through the cv2.ximgproc.guidedFilter branch of :1108-1111 instead ((2 radius + 1)^2 window,
  * BORDER_REFLECT, colour guide: per-pixel 3 x 3 covariance inverse; 1 or 3 channels; restated, parity unpinned).
  * radius 1..16.  d_out may be d_img (in place).  At the reference's radius 8 with an integer-valued table both branches run as
- * fused kernels (the a / b coefficient planes of branch 1 never leave the CU); results do not depend on which kernels run. */
+ * fused kernels (the a / b coefficient planes of branch 1 never leave the CU); branch 1 also with a float table (mean_std)
+ * whose first-stage box sums are exact in fp64 -- sr_color_table_class says which; results do not depend on which kernels run.
+ * sr_color_table_class (host only): *cls = 1 when every entry of h_glut[cn][256] is a whole number 0..255 (sums slide as
+ * 32-bit integers), 2 when a sum of `terms` values of each of g = T[v], fl32(g * v), fl32(g * g) is exact in fp64 whatever
+ * the order (all values multiples of 2^lo and below 2^hi with hi + log2(terms) - lo <= 53: sums slide in fp64), else 0
+ * (ordered sums, cv::boxFilter's order).  terms = radius^2 for branch 1. */
 SR_API int sr_histogram_u8(sr_ctx *ctx, const uint8_t *d_img, int64_t stride, int h, int w, int cn, uint64_t *h_hist);
+SR_API int sr_color_table_class(const float *h_glut, int cn, int terms, int *cls);
 SR_API int sr_color_correct_u8(sr_ctx *ctx, const uint8_t *d_img, int64_t stride, int h, int w, int cn,
                                const float *h_glut, int local_filter, int radius, float eps, uint8_t *d_out,
                                int64_t out_stride);

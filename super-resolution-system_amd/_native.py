@@ -146,6 +146,7 @@ SIGNATURES = {
     "sr_resize_cubic_window_u8": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64]),
     "sr_gray_moments_u8": (_i, [_vp, _vp, _i, _i64, _i64, _i, _i, _i, _i, C.POINTER(C.c_uint64)]),
     "sr_histogram_u8": (_i, [_vp, _vp, _i64, _i, _i, _i, C.POINTER(C.c_uint64)]),
+    "sr_color_table_class": (_i, [C.POINTER(C.c_float), _i, _i, C.POINTER(_i)]),
     "sr_color_correct_u8": (_i, [_vp, _vp, _i64, _i, _i, _i, C.POINTER(C.c_float), _i, _i, C.c_float, _vp, _i64]),
     "sr_encode_tiff_lzw": (_i, [_vp, _i, _i, _i, _i64, C.c_char_p, _i]),
     "sr_encode_png": (_i, [_vp, _i, _i, _i, _i64, _i, C.c_char_p, _i]),
@@ -369,6 +370,15 @@ def pyramid_halo(levels: int) -> Tuple[int, int]:
     a, b = C.c_int(0), C.c_int(0)
     check(load().sr_pyramid_halo(int(levels), C.byref(a), C.byref(b)))
     return a.value, b.value
+
+
+def color_table_class(glut: np.ndarray, terms: int = 64) -> int:
+    """Host-only: how the first stage of the guided filter may sum a guide table (cn x 256 float32) -- 1 whole numbers
+    (32-bit sliding sums), 2 box sums of `terms` values exact in fp64 (sliding fp64 sums), 0 ordered sums."""
+    g = np.ascontiguousarray(glut, dtype=np.float32).reshape(-1, 256)
+    cls = C.c_int(-1)
+    check(load().sr_color_table_class(g.ctypes.data_as(C.POINTER(C.c_float)), int(g.shape[0]), int(terms), C.byref(cls)))
+    return cls.value
 
 
 def ssim_count(h: int, w: int, mode: str, row_begin: int = 0, row_end: Optional[int] = None) -> int:

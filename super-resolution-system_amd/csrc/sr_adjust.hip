@@ -18,6 +18,9 @@
 //                         and other radii.
 // Byte / fp32 / ordered-fp64 stencil work, bound by VALU issue and latency rather than by HBM once a / b stay on chip; no MFMA.
 #include <algorithm>
+#include <cfloat>
+#include <climits>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -654,6 +657,253 @@ __global__ __launch_bounds__(FG_NT) void k_cc_fused8(const unsigned char *__rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 4: the same kernel for a FLOAT guide table (method 'mean_std': table[v] = (v - mean_s) * gain + mean_r, any float).
+// The first-stage maps are functions of the source byte alone -- g = T[v], s = v, g * s = fl32(T[v] * v), g * g =
+// fl32(T[v]^2) -- so the host can look at all 3 x 256 values a channel can ever add up and decide whether a box sum of
+// them is EXACT in fp64 (cc_table_class below: every value a multiple of 2^lo, |value| < 2^hi, hi + 6 - lo <= 53 for the
+// 64 addends).  Then the order of the additions is free, the sums slide (add the entering value, subtract the leaving one:
+// every intermediate is again an exactly representable multiple of 2^lo), and float(S * (1 / 64)) is the float the
+// oracle's ordered fp64 sum rounds to.  A table that fails the test (an entry very close to zero next to large ones) keeps
+// the ordered kernels (k_cc_coeff8 / k_cc_apply8).
+// fp64 column sums are 8 bytes where the integer kernel's are 4, so the maps go through the column-sum region one after
+// the other -- (g as fp64, s as u32), then g * s, then g * g: three B / C rounds per channel instead of one, the means of
+// a position kept in its thread's registers in between -- and the tile, the LDS footprint (two blocks per CU) and the
+// second stage stay as they are.  a = cov / (var + eps) is the IEEE division (a float table has no bound on var).
+// ---------------------------------------------------------------------------------------------------------------
+static_assert(FG_Y_BYTES >= FG_AH * FG_VP * 12, "fp64 + u32 column-sum planes must fit the row-sum region");
+
+template <int CN>
+__global__ __launch_bounds__(FG_NT) void k_cc_fused8f(const unsigned char *__restrict__ img, long long stride, int h, int w,
+                                                      const float *__restrict__ glutf, float eps,
+                                                      unsigned char *__restrict__ out, long long ostride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int rowb = CN * FG_IW, rawp = (rowb + 3) & ~3;
+    constexpr int LUT0 = FG_Y_BYTES + FG_X_BYTES, RAW0 = LUT0 + CN * 1024;
+    double *Vd = (double *)smem;                                  // [AH][VP] fp64 column sums of the round's map
+    unsigned *Vu = (unsigned *)(smem + FG_AH * FG_VP * 8);        // [AH][VP] column sums of s (round 0)
+    double *hs = (double *)smem;                                  // [AH][64 positions][2] in the second stage
+    float *a_p = (float *)(smem + FG_Y_BYTES), *b_p = a_p + FG_AH * FG_AP;
+    float *lutf = (float *)(smem + LUT0);                         // [CN][256]
+    unsigned char *raw = smem + RAW0;                             // [IH][rawp], pixels interleaved as in the image
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * FG_TW, y0 = blockIdx.y * FG_TH;
+
+    for (int i = tid; i < CN * 256; i += FG_NT) lutf[i] = glutf[i];
+    if (x0 >= 8 && x0 - 8 + FG_IW <= w && y0 >= 8 && y0 - 8 + FG_IH <= h) {
+        constexpr int ndw = rowb >> 2, tail = rowb & 3, per = ndw + (tail ? 1 : 0);
+        for (int e = tid; e < FG_IH * per; e += FG_NT) {
+            const int i = e / per, d = e - i * per;
+            const unsigned char *src = img + (size_t)(y0 - 8 + i) * stride + (size_t)(x0 - 8) * CN + 4 * d;
+            if (d < ndw) *(unsigned *)(raw + i * rawp + 4 * d) = *(const __attribute__((address_space(1))) fg_u32_a1_t *)src;
+            else for (int t = 0; t < tail; ++t) raw[i * rawp + 4 * d + t] = src[t];
+        }
+    } else {
+        for (int e = tid; e < FG_IH * rowb; e += FG_NT) {
+            const int i = e / rowb, r = e - i * rowb, j = r / CN, c = r - j * CN;
+            raw[i * rawp + r] = img[(size_t)cc_reflect101(y0 - 8 + i, h) * stride + (size_t)cc_reflect101(x0 - 8 + j, w) * CN + c];
+        }
+    }
+    const bool edge = y0 < 4 || y0 - 4 + FG_AH > h || x0 < 4 || x0 - 4 + FG_AW > w;   // some a / b position lies outside
+    const bool bitem = tid < FG_NSEG * FG_IW, citem = tid < FG_AH * 12;
+    const int bseg = tid / FG_IW, bcol = tid - bseg * FG_IW, br0 = min(bseg * FG_SEG, FG_AH - FG_SEG);
+    const int crow = tid / 12, cq0 = (tid - crow * 12) * 6;
+    __syncthreads();
+
+#pragma unroll
+    for (int c = 0; c < CN; ++c) {
+        const float *lt = lutf + c * 256;
+        float gf[FG_SEG + 7], sf[FG_SEG + 7];                     // pass B's column segment: guide and source values
+        float mg[6], ms[6], mgs[6];                               // pass C's positions: means of the earlier rounds
+#pragma unroll
+        for (int round = 0; round < 3; ++round) {
+            // ---- B: column sums of the round's map (round 0: g and, as integers, s) ----
+            if (bitem) {
+                double p[FG_SEG + 7];
+                unsigned su = 0;
+                if (round == 0) {
+                    const unsigned char *rp = raw + br0 * rawp + bcol * CN + c;
+                    unsigned sv[FG_SEG + 7];
+#pragma unroll
+                    for (int k = 0; k < FG_SEG + 7; ++k) {
+                        sv[k] = rp[k * rawp];
+                        gf[k] = lt[sv[k]];
+                        sf[k] = (float)sv[k];
+                        p[k] = (double)gf[k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) su += sv[k];
+#pragma unroll
+                    for (int k = 0; k < FG_SEG; ++k) {
+                        if (k > 0) su += sv[k + 7] - sv[k - 1];
+                        Vu[(br0 + k) * FG_VP + bcol] = su;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < FG_SEG + 7; ++k) {
+                        const float pr = round == 1 ? gf[k] * sf[k] : gf[k] * gf[k];   // the reference's float32 products
+                        p[k] = (double)pr;
+                    }
+                }
+                double sd = 0.0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sd += p[k];
+#pragma unroll
+                for (int k = 0; k < FG_SEG; ++k) {
+                    if (k > 0) sd += p[k + 7] - p[k - 1];
+                    Vd[(br0 + k) * FG_VP + bcol] = sd;
+                }
+            }
+            __syncthreads();
+            // ---- C: row sums; after the last round a and b ----
+            if (citem) {
+                const double *vd = Vd + crow * FG_VP + cq0;
+                double q[13], sd[6];
+#pragma unroll
+                for (int k = 0; k < 13; ++k) q[k] = vd[k];
+                sd[0] = 0.0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sd[0] += q[k];
+#pragma unroll
+                for (int t = 1; t < 6; ++t) sd[t] = sd[t - 1] + (q[t + 7] - q[t - 1]);
+                if (round == 0) {
+                    const unsigned *vu = Vu + crow * FG_VP + cq0;
+                    unsigned u[13], su[6];
+#pragma unroll
+                    for (int k = 0; k < 13; ++k) u[k] = vu[k];
+                    su[0] = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) su[0] += u[k];
+#pragma unroll
+                    for (int t = 1; t < 6; ++t) su[t] = su[t - 1] + (u[t + 7] - u[t - 1]);
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) {
+                        mg[t] = (float)(sd[t] * 0.015625);
+                        ms[t] = (float)su[t] * 0.015625f;          // an integer below 2^24: exact
+                    }
+                } else if (round == 1) {
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) mgs[t] = (float)(sd[t] * 0.015625);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) {
+                        const float mgg = (float)(sd[t] * 0.015625);
+                        const float cov = mgs[t] - mg[t] * ms[t], var = mgg - mg[t] * mg[t];
+                        const float a = cov / (var + eps);
+                        const float b = ms[t] - a * mg[t];
+                        if (cq0 + t < FG_AW) {
+                            a_p[crow * FG_AP + cq0 + t] = a;
+                            b_p[crow * FG_AP + cq0 + t] = b;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (edge) {                                               // block-uniform
+            for (int e = tid; e < FG_AH * FG_AW; e += FG_NT) {
+                const int r = e / FG_AW, q = e - r * FG_AW;
+                const int py = y0 - 4 + r, px = x0 - 4 + q;
+                if (py < 0 || py >= h || px < 0 || px >= w) {
+                    const int sr = cc_reflect101(py, h) - (y0 - 4), sq = cc_reflect101(px, w) - (x0 - 4);
+                    if (sr >= 0 && sr < FG_AH && sq >= 0 && sq < FG_AW) {   // else: a position no stored pixel reads
+                        a_p[r * FG_AP + q] = a_p[sr * FG_AP + sq];
+                        b_p[r * FG_AP + q] = b_p[sr * FG_AP + sq];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // ---- D: ordered row sums of a and b (as in k_cc_fused8) ----
+        for (int e = tid; e < FG_AH * 16; e += FG_NT) {
+            const int py = e >> 4, gx = e & 15;
+            const float4 *ar = (const float4 *)(a_p + py * FG_AP + 4 * gx), *br = (const float4 *)(b_p + py * FG_AP + 4 * gx);
+            const float4 a0 = ar[0], a1 = ar[1], a2 = ar[2], b0 = br[0], b1 = br[1], b2 = br[2];
+            const double v0[11] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z};
+            const double v1[11] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z};
+            double o0[4], o1[4];
+            fg_sums(v0, o0);
+            fg_sums(v1, o1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *(double2 *)(hs + ((size_t)py * FG_TW + j * 16 + gx) * 2) = make_double2(o0[j], o1[j]);
+        }
+        __syncthreads();
+        // ---- E: ordered column sums, output ----
+        {
+            const int gy = tid >> 6, l = tid & 63, ox = 4 * (l & 15) + (l >> 4);
+            double v0[11], v1[11];
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                const double2 t = *(const double2 *)(hs + ((size_t)(4 * gy + k) * FG_TW + l) * 2);
+                v0[k] = t.x;
+                v1[k] = t.y;
+            }
+            double ta[4], tb[4];
+            fg_sums(v0, ta);
+            fg_sums(v1, tb);
+            unsigned char *px = raw + (4 * gy + 8) * rawp + (ox + 8) * CN + c;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float ma = (float)(ta[j] * 0.015625), mb = (float)(tb[j] * 0.015625);
+                const float g = lt[px[j * rawp]];
+                const float r = ma * g + mb;
+                const float cl = r < 0.0f ? 0.0f : (r > 255.0f ? 255.0f : r);     // k_cc_apply8's clip, also for a NaN
+                px[j * rawp] = (unsigned char)cl;
+            }
+        }
+        __syncthreads();                                          // hs becomes the column-sum planes again
+    }
+    constexpr int tileb = FG_TW * CN;
+    if (x0 + FG_TW <= w && y0 + FG_TH <= h) {
+        constexpr int ndw = tileb >> 2;
+        for (int e = tid; e < FG_TH * ndw; e += FG_NT) {
+            const int oy = e / ndw, d = e - oy * ndw;
+            *(__attribute__((address_space(1))) fg_u32_a1_t *)(out + (size_t)(y0 + oy) * ostride + (size_t)x0 * CN + 4 * d) =
+                *(const unsigned *)(raw + (oy + 8) * rawp + 8 * CN + 4 * d);
+        }
+    } else {
+        const int vw = min(FG_TW, w - x0) * CN, vh = min(FG_TH, h - y0);
+        for (int e = tid; e < vh * tileb; e += FG_NT) {
+            const int oy = e / tileb, r = e - oy * tileb;
+            if (r < vw) out[(size_t)(y0 + oy) * ostride + (size_t)x0 * CN + r] = raw[(oy + 8) * rawp + 8 * CN + r];
+        }
+    }
+}
+
+// What the first stage of the radius-8 guided filter may do with a guide table (host only):
+//   1  every entry a whole number 0..255: the integer kernel (k_cc_fused8),
+//   2  a float table whose box sums of `terms` addends are exact in fp64 (see k_cc_fused8f): sliding fp64 sums,
+//   0  neither: ordered sums (k_cc_coeff8 / k_cc_apply8).
+static int cc_table_class(const float *tab, int cn, int terms)
+{
+    bool whole = true;
+    for (int i = 0; i < cn * 256 && whole; ++i) {
+        const float v = tab[i];
+        whole = v >= 0.0f && v <= 255.0f && v == (float)(int)v;
+    }
+    if (whole) return 1;
+    int tbits = 0;
+    while ((1 << tbits) < terms) ++tbits;
+    for (int c = 0; c < cn; ++c) {
+        for (int m = 0; m < 3; ++m) {
+            int lo = INT_MAX, hi = INT_MIN;
+            for (int v = 0; v < 256; ++v) {
+                const float g = tab[c * 256 + v];
+                volatile float x = m == 0 ? g : (m == 1 ? g * (float)v : g * g);      // rounded to float32, as on the device
+                const float ax = fabsf(x);
+                if (!(ax <= FLT_MAX)) return 0;                                        // inf / NaN
+                if (ax == 0.0f) continue;
+                const int e = ilogbf(ax);                                              // 2^e <= |x| < 2^(e + 1)
+                lo = std::min(lo, std::max(e, -126) - 23);
+                hi = std::max(hi, e + 1);
+            }
+            if (lo != INT_MAX && hi + tbits - lo > 53) return 0;
+        }
+    }
+    return 2;
+}
+
 
 // ---------------------------------------------------------------------------------------------------------------
 // The OTHER branch of BlendingModule._guided_filter (blending_module.py:1108-1111): cv2.ximgproc.guidedFilter(guide, src,
@@ -1175,6 +1425,14 @@ int sr_gray_moments_u8(sr_ctx *ctx, const uint8_t *d_tiles, int n, int64_t tile_
     return SR_OK;
 }
 
+int sr_color_table_class(const float *h_glut, int cn, int terms, int *cls)
+{
+    if (!h_glut || !cls || cn < 1 || cn > 4 || terms < 1 || terms > 4096)
+        return sr_set_error(SR_ERR_INVALID_ARG, "sr_color_table_class: bad arguments");
+    *cls = cc_table_class(h_glut, cn, terms);
+    return SR_OK;
+}
+
 int sr_color_correct_u8(sr_ctx *ctx, const uint8_t *d_img, int64_t stride, int h, int w, int cn, const float *h_glut,
                         int local_filter, int radius, float eps, uint8_t *d_out, int64_t out_stride)
 {
@@ -1301,16 +1559,17 @@ int sr_color_correct_u8(sr_ctx *ctx, const uint8_t *d_img, int64_t stride, int h
     // (the fused kernel's division leaves out v_div_scale / v_div_fixup, the identity while var + eps stays in [0.006, 65026]:
     // true for the reference's eps = 0.01, not for an arbitrary one -- a smaller eps takes the pass-structured kernels and
     // their IEEE division, so results never depend on which kernels run)
-    if (radius == CC8_R && h >= 16 && w >= 16 && !in_place && eps >= 0.005f && !env_flag_off("SR_CC_FUSED")) {
-        // the reference's setting with an integer-valued guide table (histogram matching, method 'none'): one fused kernel
-        unsigned char tabb[4 * 256];
-        bool whole = true;
-        for (int i = 0; i < cn * 256 && whole; ++i) {
-            const float v = h_glut[i];
-            whole = v >= 0.0f && v <= 255.0f && v == (float)(int)v;
-            tabb[i] = (unsigned char)(whole ? (int)v : 0);
-        }
-        if (whole) {
+    if (radius == CC8_R && h >= 16 && w >= 16 && !in_place && !env_flag_off("SR_CC_FUSED")) {
+        // the reference's radius with a table whose first-stage sums may slide: one fused kernel
+        //   class 1 (histogram matching, method 'none': whole numbers) -> k_cc_fused8, exact 32-bit sums;
+        //   class 2 (a mean_std table whose fp64 box sums are exact)    -> k_cc_fused8f, exact fp64 sums, IEEE division
+        // (an integer table with eps < 0.005 is exact as a float table too and takes the second kernel)
+        int cls = cc_table_class(h_glut, cn, CC8_R * CC8_R);
+        if (cls == 1 && eps < 0.005f) cls = 2;
+        if (cls == 2 && env_flag_off("SR_CC_FUSED_F")) cls = 0;
+        if (cls == 1) {
+            unsigned char tabb[4 * 256];
+            for (int i = 0; i < cn * 256; ++i) tabb[i] = (unsigned char)(int)h_glut[i];
             unsigned char *d_glutb = (unsigned char *)scr + tab_bytes;
             HIPCHK(upload_small(ctx, d_glutb, tabb, (size_t)cn * 256));
             const size_t lds = (size_t)FG_Y_BYTES + FG_X_BYTES + 1024 + (size_t)FG_IH * ((cn * FG_IW + 3) & ~3);
@@ -1332,6 +1591,27 @@ int sr_color_correct_u8(sr_ctx *ctx, const uint8_t *d_img, int64_t stride, int h
 #undef FG_LAUNCH
             }
             return check_launch("guided_fused");
+        }
+        if (cls == 2) {
+            const size_t lds = (size_t)FG_Y_BYTES + FG_X_BYTES + (size_t)cn * 1024 + (size_t)FG_IH * ((cn * FG_IW + 3) & ~3);
+            const void *kf = cn == 1 ? (const void *)k_cc_fused8f<1> : cn == 2 ? (const void *)k_cc_fused8f<2>
+                             : cn == 3 ? (const void *)k_cc_fused8f<3> : (const void *)k_cc_fused8f<4>;
+            (void)hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            {
+                ProfScope ps(ctx, "guided_fused_f");
+                const dim3 grid((w + FG_TW - 1) / FG_TW, (h + FG_TH - 1) / FG_TH);
+                const float *lf = d_glut;
+#define FG_LAUNCH(N) hipLaunchKernelGGL(k_cc_fused8f<N>, grid, dim3(FG_NT), lds, ctx->stream, d_img, (long long)stride, h, w, lf, eps, \
+                                        d_out, (long long)out_stride)
+                switch (cn) {
+                case 1: FG_LAUNCH(1); break;
+                case 2: FG_LAUNCH(2); break;
+                case 3: FG_LAUNCH(3); break;
+                default: FG_LAUNCH(4); break;
+                }
+#undef FG_LAUNCH
+            }
+            return check_launch("guided_fused_f");
         }
     }
     // a / b planes (8 bytes per sample): an allocation of their own, released when the call is done

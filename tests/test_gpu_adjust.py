@@ -105,6 +105,60 @@ def test_color_correction_fused_guided_filter(rng, shape, monkeypatch):
     assert np.array_equal(bm.color_correction(noise, ref), onp.color_correction(noise, ref))
 
 
+@pytest.mark.parametrize("shape", [(16, 16, 3), (17, 64, 3), (40, 71, 1), (97, 211, 3), (33, 130, 4), (200, 300, 3), (64, 128, 2),
+                                   (46, 78, 3), (47, 79, 1)])
+def test_color_correction_fused_guided_filter_float_table(ctx, rng, shape, monkeypatch):
+    """The one-kernel guided filter with a FLOAT guide table (k_cc_fused8f: 'mean_std' tables whose box sums are exact in
+    fp64 slide; sr_color_table_class == 2) against the oracle's ordered sums AND against the pass-structured kernels
+    (SR_CC_FUSED_F=0): interiors, borders, ragged edges, 1-4 channels; tables with negative entries and entries above 255;
+    a table with an entry next to zero (class 0) must take the ordered kernels and still agree."""
+    import _native
+    h, w, cn = shape
+    img = _scene(rng, h, w, cn)
+    src = img.astype(np.float32)
+    base = np.arange(256, dtype=np.float32)[None, :]
+    tables = {
+        "mean_std": (base - rng.uniform(60, 180, (cn, 1)).astype(np.float32)) * rng.uniform(0.3, 1.9, (cn, 1)).astype(np.float32)
+                    + rng.uniform(60, 180, (cn, 1)).astype(np.float32),
+        "wide": (base - np.float32(140.25)) * np.float32(2.5) + np.float32(100.5),          # -250 .. 387
+        "near_zero": (base - np.float32(100.0)) * np.float32(1.0009765625) + np.float32(2.0 ** -12),
+    }
+    classes = {k: _native.color_table_class(v if v.shape[0] == cn else np.repeat(v, cn, 0)) for k, v in tables.items()}
+    assert classes["wide"] == 2 and classes["near_zero"] == 0, classes
+    for name, lut in tables.items():
+        lut = np.ascontiguousarray(lut if lut.shape[0] == cn else np.repeat(lut, cn, 0))
+        corrected = np.stack([lut[c][img[..., c]] for c in range(cn)], axis=-1).astype(np.float32)
+        want = np.clip(onp.simple_guided_filter(corrected, src, 8, 0.01), 0, 255).astype(np.uint8)
+
+        def run():
+            d, o = ctx.upload(img), ctx.alloc(img.size)
+            ctx.color_correct_u8(d.ptr, w * cn, h, w, cn, lut, 1, 8, 0.01, o.ptr, w * cn)
+            got = ctx.download(o.ptr, img.shape, np.uint8)
+            d.free(); o.free()
+            return got
+        got = run()
+        assert np.array_equal(got, want), (shape, name, classes[name], int((got != want).sum()))
+        monkeypatch.setenv("SR_CC_FUSED_F", "0")
+        two_pass = run()
+        monkeypatch.delenv("SR_CC_FUSED_F")
+        assert np.array_equal(two_pass, want), (shape, name)
+
+
+def test_color_correction_small_eps_takes_ieee_division(ctx, rng):
+    """eps below 0.005 (the integer kernel's bare fma-chain division is only proven for the reference's 0.01): an integer
+    table then runs through the float-table kernel and its IEEE division; fused and pass-structured results agree with the
+    oracle."""
+    img = _scene(rng, 70, 131)
+    lut = np.tile(np.arange(256, dtype=np.float32), (3, 1))
+    for eps in (1e-3, 1e-4):
+        d, o = ctx.upload(img), ctx.alloc(img.size)
+        ctx.color_correct_u8(d.ptr, 131 * 3, 70, 131, 3, lut, 1, 8, eps, o.ptr, 131 * 3)
+        got = ctx.download(o.ptr, img.shape, np.uint8)
+        d.free(); o.free()
+        want = np.clip(onp.simple_guided_filter(img.astype(np.float32), img.astype(np.float32), 8, eps), 0, 255).astype(np.uint8)
+        assert np.array_equal(got, want), (eps, int((got != want).sum()))
+
+
 @pytest.mark.parametrize("mode,guided", [(1, "simple"), (2, "ximgproc")])
 def test_color_correct_in_place(ctx, rng, mode, guided):
     """sr_color_correct_u8 with the output buffer ON the input: the fused kernels read a block's halo while other blocks store,

@@ -179,3 +179,56 @@ def test_non_u8_seams_and_color_correction_raise_pinned_types():
     with pytest.raises(NotImplementedError):
         bm.color_correction(u8, u8.astype(np.int16), method="mean_std")
     assert bm.color_correction(u8.astype(np.float64), u8, method="none").dtype == np.float64                     # 'none' returns the input
+
+
+def test_color_table_class_and_the_exactness_it_promises():
+    """sr_color_table_class (host only): 1 = whole numbers, 2 = a float table whose box sums of 64 values of g, fl32(g * v),
+    fl32(g * g) are exact in fp64 (the fused guided filter then slides them), 0 = ordered sums.  For class-2 tables the
+    promise is checked directly: 64 random table values summed in float64 in three different orders (the oracle's
+    sequential order, reversed, sorted by magnitude) and with a sliding update give one and the same double."""
+    import _native
+    rng = np.random.default_rng(5)
+    ident = np.tile(np.arange(256, dtype=np.float32), (3, 1))
+    assert _native.color_table_class(ident) == 1
+    assert _native.color_table_class(ident[:1] * np.float32(0.5)) in (0, 2) and _native.color_table_class(ident * np.float32(0.5)) == 2
+    bad = ident.copy()
+    bad[1, 7] = np.float32(2.0 ** -20)
+    assert _native.color_table_class(bad) == 0
+    bad[1, 7] = np.nan
+    assert _native.color_table_class(bad) == 0
+    bad[1, 7] = np.inf
+    assert _native.color_table_class(bad) == 0
+    with pytest.raises(ValueError):
+        _native.color_table_class(ident, terms=0)
+    n2 = 0
+    for _ in range(200):
+        t = ((np.arange(256, dtype=np.float32) - np.float32(rng.uniform(20, 230))) * np.float32(rng.uniform(0.2, 3.0))
+             + np.float32(rng.uniform(0, 255)))[None, :]
+        cls = _native.color_table_class(t)
+        assert cls in (0, 2)
+        if cls != 2:
+            continue
+        n2 += 1
+        v = rng.integers(0, 256, 72)
+        g = t[0][v]
+        for m in (g, g * v.astype(np.float32), g * g):
+            assert m.dtype == np.float32
+            x = m.astype(np.float64)
+            seq = 0.0
+            for e in x[:64]:
+                seq += e
+            rev = 0.0
+            for e in x[:64][::-1]:
+                rev += e
+            srt = 0.0
+            for e in sorted(x[:64], key=abs):
+                srt += e
+            assert seq == rev == srt
+            slide = seq
+            for k in range(8):                                   # the window moves on by 8: add the entering, drop the leaving value
+                slide += x[64 + k] - x[k]
+            want = 0.0
+            for e in x[8:72]:
+                want += e
+            assert slide == want
+    assert n2 > 100            # most mean_std tables qualify; those with an entry next to zero do not

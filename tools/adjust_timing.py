@@ -26,7 +26,7 @@ tw, th = geo.rects[0][2], geo.rects[0][3]
 tiles = torch.randint(0, 256, (len(geo.rects), th, tw * cn), dtype=torch.uint8, device=dev, generator=g)
 
 
-# a `mean_std` table (blending_module._mean_std_table): float values, not integers -- the fused kernels' exact integer sums do not apply
+# a `mean_std` table (blending_module._mean_std_table): float values, not integers -- class 2 of sr_color_table_class: fp64 sliding sums (k_cc_fused8f)
 lut_f = np.clip((lut - 120.0) * np.float32(1.07) + np.float32(131.3), 0, 255).astype(np.float32)
 EPS = 0.01                    # the reference's eps (blending_module.py:1092-1146)
 
@@ -60,4 +60,6 @@ def timed(table):
 res_int, res_float = timed(lut), timed(lut_f)
 print(json.dumps({"image": f"{W}x{H}", "tiles": f"{len(geo.rects)} x {tw}x{th}", "eps": EPS,
                   "integer_table": res_int, "float_table": res_float,
+                  "table_class": {"integer_table": _native.color_table_class(lut), "float_table": _native.color_table_class(lut_f)},
+                  "fused_float": os.environ.get("SR_CC_FUSED_F", "1") != "0",
                   "bytes_GB": {"histogram": round(H * W * cn / 1e9, 3), "lut_apply": round(2 * H * W * cn / 1e9, 3)}}))
