@@ -10,8 +10,9 @@
 //                         row sums top to bottom; mean = (float)(sum * (1.0 / (r * r))).  Separable through LDS: a block
 //                         owns 64 x 16 output pixels of one channel at a time.  Since round 3 the reference's setting (radius 8,
 //                         integer-valued guide table) is ONE kernel, k_cc_fused8: exact 32-bit sliding sums for the first
-//                         stage, a and b kept in LDS (9.9 -> 3.4 ms at 200 MP); the passes above remain for float tables
-//                         and other radii.
+//                         stage, a and b kept in LDS (9.9 -> 3.4 ms at 200 MP); round 4: k_cc_fused8f does the same with
+//                         fp64 sliding sums for a float (mean_std) table whose box sums are provably exact (cc_table_class;
+//                         9.9 -> 4.3 ms); the passes above remain for the other float tables and other radii.
 //   cv2.ximgproc.guidedFilter (the branch a requirements-complete install takes; parity unpinned): k_gfx_coeff17 (all 21 first-
 //                         stage means + the 3 x 3 inverse in one kernel, integer tables) and k_gf_box17_out (second stage +
 //                         output per channel); k_gf_box / k_gf_box17 / k_gf_coeff / k_gf_out for float tables, gray images

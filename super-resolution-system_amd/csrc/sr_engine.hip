@@ -1794,6 +1794,110 @@ __global__ __launch_bounds__(FU_THREADS, FU_WAVES) void k_final_fused(const Fina
     if (alive) store_pixels<CN>(acc, wacc, canvas, cstride, canvas_f32, cw, x0, y0, nx, ny);   // ragged cells without a visit: zeros
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 4: what the marched zones leave -- thin bands along the tiles' edges, 1.8 % of the cells of the 200 MP grid -- as
+// RECTANGLES of cells (k_final_rect).  The 128 x 16 blocks above cut a vertical band 3-5 cells wide into 722 blocks per band
+// with 30-40 of their 256 cells in use, and the cells with a border visit were visited a second time by the edge blocks
+// (window built twice): 9 192 + 2 700 blocks, 12 rounds of dependent round trips, 0.21 ms for 3.5 MP.  A rectangle item is
+// w x h cells with w * h <= 256 and a level-1 window that fits the LDS planes (a band 5 cells wide: 5 x 51 cells, a band 6
+// rows high: 32 x 6); every cell of it is finished here, whatever its visits are -- interior visits through the packed
+// path, border visits through the per-pixel rules (fused_edge_block's two paths; the same expressions, bit-identical) -- so
+// the edge blocks are not launched at all beside a march.  Threads are dealt column-major over tall rectangles: along a
+// vertical tile edge the kind of visit is then uniform per wave.
+// ---------------------------------------------------------------------------------------------
+struct RectItem {                    // 32 bytes, block-uniform
+    int x, y;                        // canvas pixel of the first cell (y includes row_begin)
+    int w, h;                        // cells across / down
+    int cand, ncand;                 // candidate tiles: rect_cand[cand .. cand + ncand), list order
+    int lp;                          // LDS pitch of the level-1 window (floats pairs per row)
+    int colmajor;                    // 1: thread -> (column, row) with rows fastest
+};
+static_assert(sizeof(RectItem) == 32, "RectItem layout");
+
+// window columns / rows fused_window can ask for, for a rectangle of w x h cells (host and static checks)
+static inline int rect_lp(int w) { return 4 * ((2 * w + 4) / 4) + 4; }
+static inline int rect_rows(int h) { return 2 * ((h + 2) / 2) + 2; }
+
+template <int CN>
+__global__ __launch_bounds__(FU_THREADS, FU_WAVES) void k_final_rect(const FinalDesc *__restrict__ descs, const RectItem *__restrict__ rects,
+                                                        const int *__restrict__ rect_cand, const float *__restrict__ arena,
+                                                        const float *__restrict__ luts, unsigned char *__restrict__ canvas,
+                                                        long long cstride, float *__restrict__ canvas_f32, int cw, int row_begin,
+                                                        int row_end)
+{
+    constexpr int DT = SRC_U8;
+    __shared__ __attribute__((aligned(16))) float lds[2 * CN * FU_PLANE];
+    const RectItem it = rects[blockIdx.x];
+    const int tid = threadIdx.x;
+    int scx, scy;
+    if (it.colmajor) {
+        scx = tid / it.h;
+        scy = tid - scx * it.h;
+    } else {
+        scy = tid / it.w;
+        scx = tid - scy * it.w;
+    }
+    const int x0 = it.x + 4 * scx, y0 = it.y + 2 * scy;
+    const bool inside = scx < it.w && scy < it.h && x0 < cw && y0 < row_end;
+    const int nx = min(4, cw - x0), ny = min(2, row_end - y0);
+    const int LP = it.lp;
+    float acc[2][4][CN], wacc[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            wacc[j][k] = 0.f;
+#pragma unroll
+            for (int c = 0; c < CN; ++c) acc[j][k][c] = 0.f;
+        }
+    for (int i = it.cand; i < it.cand + it.ncand; ++i) {
+        const FinalDesc &D = descs[rect_cand[i]];
+        const int lxa = it.x - D.x, lya = it.y - D.y;
+        int R0 = 0, C0 = 0, npr = 0, npc = 0;
+        const bool win = D.nl > 1 && fused_window(D, lxa, lya, 4 * it.w, 2 * it.h, R0, C0, npr, npc);     // block-uniform
+        const int lx0 = x0 - D.x, ly0 = y0 - D.y;
+        const bool touches = inside && !(lx0 + nx <= 0 || ly0 + ny <= 0 || lx0 >= D.w || ly0 >= D.h);
+        const bool inner = touches && visit_is_interior<true>(D, lx0, ly0, nx, ny);
+        CellPixels<DT, CN> cp;
+        if (inner) fused_load_pixels<DT, CN>(D, lx0, ly0, cp);                                        // in flight during stage 1
+        if (win) fused_stage1<CN>(D, arena, lds, R0, C0, npr, npc, LP, tid);
+        __syncthreads();
+        const bool xo = (D.x & 1) != 0;                      // x0 is a multiple of 4
+        const bool yo = ((row_begin - D.y) & 1) != 0;        // y0 - row_begin is a multiple of 2
+        if (inner) {
+            const bool codd = D.nl > 1 && ((((lxa - 1) >> 1) - C0) & 1) != 0;   // parity of every cell's first tap column (block-uniform)
+#define FR_CALL(XOV, YOV, CV) fused_gather_fast<DT, CN, XOV, YOV, CV>(D, luts, lds, LP, R0, C0, lx0, ly0, cp, acc, wacc)
+            if (!codd) {
+                if (!xo && !yo) FR_CALL(false, false, false);
+                else if (xo && !yo) FR_CALL(true, false, false);
+                else if (!xo && yo) FR_CALL(false, true, false);
+                else FR_CALL(true, true, false);
+            } else {
+                if (!xo && !yo) FR_CALL(false, false, true);
+                else if (xo && !yo) FR_CALL(true, false, true);
+                else if (!xo && yo) FR_CALL(false, true, true);
+                else FR_CALL(true, true, true);
+            }
+#undef FR_CALL
+        }
+        if (touches && !inner) {
+            unsigned valid = 0;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (j < ny && k < nx && lx0 + k >= 0 && lx0 + k < D.w && ly0 + j >= 0 && ly0 + j < D.h)
+                        valid |= 1u << (j * 4 + k);
+            if (!xo && !yo) fused_gather_generic<DT, CN, false, false>(D, luts, lds, LP, R0, C0, lx0, ly0, valid, acc, wacc);
+            else if (xo && !yo) fused_gather_generic<DT, CN, true, false>(D, luts, lds, LP, R0, C0, lx0, ly0, valid, acc, wacc);
+            else if (!xo && yo) fused_gather_generic<DT, CN, false, true>(D, luts, lds, LP, R0, C0, lx0, ly0, valid, acc, wacc);
+            else fused_gather_generic<DT, CN, true, true>(D, luts, lds, LP, R0, C0, lx0, ly0, valid, acc, wacc);
+        }
+        __syncthreads();                                       // the next tile's stage 1 overwrites the window
+    }
+    if (inside) store_pixels<CN>(acc, wacc, canvas, cstride, canvas_f32, cw, x0, y0, nx, ny);   // cells without a visit: zeros
+}
+
 #include "sr_march.inc"
 #include "sr_down2.inc"
 
@@ -3070,6 +3174,9 @@ struct sr_blend_plan {
     long long n_march_total = 0;
     int *d_freg_list = nullptr, *d_freg_all = nullptr;      // without the marched zones / every regular block (float tiles): 9 ints each
     long long n_freg = 0, n_freg_all = 0;
+    RectItem *d_rects = nullptr;                            // what the marched zones leave, as rectangles of cells (k_final_rect)
+    int *d_rect_cand = nullptr;
+    long long n_rects = 0;
     std::vector<char> sh_srcs, sh_fdesc;                // host shadows of d_srcs / d_fdesc (upload_if_changed)
     CachedTable subset_tabs[4];                         // compacted {TileDev, TileSrc} tables of recent tile subsets
     int subset_next = 0;
@@ -3093,12 +3200,12 @@ static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // the mask of its marched cell columns.
 // ---------------------------------------------------------------------------------------------
 static void plan_march(const sr_blend_plan *P, int nbx_r, int nby_r, std::vector<MarchItem> (&items)[MARCH_NT + 1],
-                       std::vector<int> &reg_list)
+                       std::vector<int> &reg_list, std::vector<unsigned> &cover)
 {
     const int rows = P->row_end - P->row_begin, cw = P->canvas_w, n = P->n;
     const int ncx = cw / 4, ncy = rows / 2;                    // whole cells only: ragged ends are border visits
     const int CPB = FU_BH / 2;                                 // cell rows per regular block
-    std::vector<unsigned> cover((size_t)nbx_r * nby_r * CPB, 0u);          // [block row][cell row][block column]: cell column bits
+    cover.assign((size_t)nbx_r * nby_r * CPB, 0u);                         // [cell row][block column]: cell column bits (1 = marched)
     // the marched kernels address the arena and a tile's pixels with 32-bit byte offsets (buffer instructions)
     bool fits32 = P->arena_floats * sizeof(float) < 0xFFFF0000ull && (unsigned long long)cw * P->cn * 4ull * (2 * MARCH_SEG + 2) < 0xFFFF0000ull;
     for (int t = 0; t < n && fits32; ++t) fits32 = (unsigned long long)P->tiles[t].h * P->tiles[t].w * P->cn * 4ull < 0x7FFF0000ull;
@@ -3197,28 +3304,47 @@ static void plan_march(const sr_blend_plan *P, int nbx_r, int nby_r, std::vector
         // Segment length per tile count: as long as MARCH_SEG steps where that still leaves every wave slot of the GPU a few
         // items (the warm-up of an item costs about two steps), shorter where a list is small -- a short list of long items
         // is a latency-bound launch of one or two rounds.
-        long long steps_of[MARCH_NT + 1] = {0};
-        for (const Strip &st : strips) steps_of[st.nt] += st.ye - st.ya;
+        long long steps_of[MARCH_NT + 1] = {0}, cells_of[MARCH_NT + 1] = {0};
+        for (const Strip &st : strips) {
+            steps_of[st.nt] += st.ye - st.ya;
+            cells_of[st.nt] += (long long)(st.ye - st.ya) * (st.cb - st.ca);
+        }
         for (int nt = 1; nt <= MARCH_NT; ++nt) {
             if (!steps_of[nt]) continue;
             const long long want_items = (long long)P->ctx->num_cu * 8 / nt * 6;           // six rounds at two waves per SIMD
             int seg = (int)std::min<long long>(MARCH_SEG, std::max<long long>(8, steps_of[nt] / want_items));
             seg = seg / 2 * 2;
+            // The items of a list run in list order, a few rounds of them: the last round leaves the GPU emptier and emptier
+            // while its long items finish (half an item's duration per launch, ~30 us of march1's 300).  So the list ends
+            // with short items: the last `tail` strip-steps (about one round of full-length items) are cut into segments of
+            // half the length, the last quarter of those into the shortest ones (8 steps: an item's warm-up is ~2).
+            // SR_MARCH_TAIL=0: uniform segments (A/B runs).  Which segment a canvas row falls into changes no value.
+            static const bool taper = !(std::getenv("SR_MARCH_TAIL") && std::getenv("SR_MARCH_TAIL")[0] == '0');
+            const long long slots = std::max<long long>((long long)P->ctx->num_cu * 8 / nt, 1);
+            const long long tail = taper && seg > 8 ? std::min<long long>(slots * seg, steps_of[nt] / 3) : 0;
+            long long done = 0;
             for (const Strip &st : strips) {
                 if (st.nt != nt) continue;
-                for (int sy = st.ya; sy < st.ye; sy += seg) {
+                for (int sy = st.ya; sy < st.ye;) {
+                    const long long left = steps_of[nt] - done;
+                    int sg = seg;
+                    if (left <= tail / 4) sg = 8;
+                    else if (left <= tail) sg = std::max(8, seg / 4 * 2);
                     MarchItem it;
                     memset(&it, 0, sizeof(it));
                     it.x0 = 4 * (st.ca - 1);
                     it.y0 = P->row_begin + 2 * sy;
                     it.ncell = st.cb - st.ca;
-                    it.nstep = std::min(seg, st.ye - sy);
+                    it.nstep = std::min(sg, st.ye - sy);
                     for (int k = 0; k < nt; ++k) it.tile[k] = st.tile[k];
                     items[nt].push_back(it);
+                    sy += it.nstep;
+                    done += it.nstep;
                 }
             }
             if (std::getenv("SR_MARCH_STATS"))
-                fprintf(stderr, "[march] %d-tile zones: %lld strip-steps, segments of %d steps, %zu items\n", nt, steps_of[nt], seg, items[nt].size());
+                fprintf(stderr, "[march] %d-tile zones: %lld strip-steps, %lld cells (%.2f %% of %d x %d), segments of %d steps, %zu items\n", nt,
+                        steps_of[nt], cells_of[nt], 100.0 * (double)cells_of[nt] / ((double)ncx * ncy), ncx, ncy, seg, items[nt].size());
         }
     }
     // the regular blocks that still hold unmarched cells: block id + the marched cell columns of each of its CPB cell rows
@@ -3238,6 +3364,88 @@ static void plan_march(const sr_blend_plan *P, int nbx_r, int nby_r, std::vector
             reg_list.push_back(by * nbx_r + bx);
             for (int cy = 0; cy < CPB; ++cy) reg_list.push_back((int)m[cy]);
         }
+    if (std::getenv("SR_MARCH_STATS")) {
+        long long left = 0;
+        for (size_t i = 0; i < reg_list.size(); i += 9)
+            for (int cy = 0; cy < CPB; ++cy) left += 32 - __builtin_popcount((unsigned)reg_list[i + 1 + cy]);
+        fprintf(stderr, "[march] block kernel: %zu regular blocks of %d x %d with %lld unmarched cell slots (%.2f %% of the canvas cells)\n",
+                reg_list.size() / 9, nbx_r, nby_r, left, 100.0 * (double)left / ((double)ncx * ncy));
+    }
+}
+
+// What the marched zones leave, cut into rectangles of cells for k_final_rect: every cell row's runs of unmarched cells --
+// a narrow run (<= 8 cells: a band along a vertical tile edge) whole, a wide one in pieces that end on multiples of 32 cells
+// -- stacked downwards while the next row holds the same piece and the rectangle still fits 256 threads and the LDS window.
+// cover: plan_march's bitmap (row pitch nbx_r words); ragged cells at the right / bottom end are unmarched cells like any other.
+static void plan_rects(const sr_blend_plan *P, int nbx_r, const std::vector<unsigned> &cover, std::vector<RectItem> &rects,
+                       std::vector<int> &rcand)
+{
+    const int rows = P->row_end - P->row_begin, cw = P->canvas_w;
+    const int ncxp = (cw + 3) / 4, ncyp = (rows + 1) / 2;
+    auto hmax = [](int w) {
+        int h = 256 / w;
+        while (h > 1 && rect_rows(h) * rect_lp(w) > FU_PLANE) --h;
+        return h;
+    };
+    struct Open { int ya, h; };
+    std::map<std::pair<int, int>, Open> open;                     // (first cell column, end) -> rectangle still growing
+    auto emit = [&](int xa, int xb, int ya, int h) {
+        RectItem it;
+        it.x = 4 * xa;
+        it.y = P->row_begin + 2 * ya;
+        it.w = xb - xa;
+        it.h = h;
+        it.cand = (int)rcand.size();
+        const long long bx0 = it.x, bx1 = std::min<long long>(bx0 + 4ll * it.w, cw);
+        const long long by0 = it.y, by1 = std::min<long long>(by0 + 2ll * it.h, P->row_end);
+        for (int t = 0; t < P->n; ++t) {
+            const TileDev &T = P->tiles[t];
+            if (T.x < bx1 && (long long)T.x + T.w > bx0 && T.y < by1 && (long long)T.y + T.h > by0) rcand.push_back(t);
+        }
+        it.ncand = (int)rcand.size() - it.cand;
+        it.lp = rect_lp(it.w);
+        it.colmajor = it.h > it.w ? 1 : 0;
+        rects.push_back(it);
+    };
+    std::vector<std::pair<int, int>> segs;
+    for (int cy = 0; cy < ncyp; ++cy) {
+        segs.clear();
+        const unsigned *row = cover.data() + (size_t)cy * nbx_r;
+        for (int cx = 0; cx < ncxp;) {
+            const unsigned wd = row[cx >> 5];
+            if ((cx & 31) == 0 && wd == 0xFFFFFFFFu) { cx += 32; continue; }
+            if ((wd >> (cx & 31)) & 1u) { ++cx; continue; }
+            int xe = cx;
+            while (xe < ncxp && !((row[xe >> 5] >> (xe & 31)) & 1u)) ++xe;
+            if (xe - cx <= 8) segs.emplace_back(cx, xe);
+            else
+                for (int a = cx; a < xe;) {
+                    const int b = std::min(xe, (a / 32 + 1) * 32);
+                    segs.emplace_back(a, b);
+                    a = b;
+                }
+            cx = xe;
+        }
+        std::map<std::pair<int, int>, Open> next;
+        for (const auto &sg : segs) {
+            auto f = open.find(sg);
+            if (f != open.end() && f->second.h < hmax(sg.second - sg.first)) {
+                next[sg] = Open{f->second.ya, f->second.h + 1};
+                open.erase(f);
+            } else {
+                next[sg] = Open{cy, 1};                               // (a full one stays in `open` and is closed below)
+            }
+        }
+        for (const auto &o : open) emit(o.first.first, o.first.second, o.second.ya, o.second.h);
+        open.swap(next);
+    }
+    for (const auto &o : open) emit(o.first.first, o.first.second, o.second.ya, o.second.h);
+    if (std::getenv("SR_MARCH_STATS")) {
+        long long cells = 0;
+        for (const RectItem &r : rects) cells += (long long)r.w * r.h;
+        fprintf(stderr, "[march] rectangles of the remainder: %zu items, %lld cells (%.1f per item), %zu candidate visits\n", rects.size(), cells,
+                rects.empty() ? 0.0 : (double)cells / (double)rects.size(), rcand.size());
+    }
 }
 
 bool plan_describe(const sr_blend_plan *p, sr_ctx **ctx, int *n, int *cn)
@@ -3618,6 +3826,8 @@ int sr_blend_plan_destroy(sr_blend_plan *plan)
         if (plan->d_fedge_cand) (void)hipFree(plan->d_fedge_cand);
         if (plan->d_freg_list) (void)hipFree(plan->d_freg_list);
         if (plan->d_freg_all) (void)hipFree(plan->d_freg_all);
+        if (plan->d_rects) (void)hipFree(plan->d_rects);
+        if (plan->d_rect_cand) (void)hipFree(plan->d_rect_cand);
         for (int k = 0; k <= MARCH_NT; ++k)
             if (plan->d_march_items[k]) (void)hipFree(plan->d_march_items[k]);
         for (auto &t : plan->subset_tabs)
@@ -3993,7 +4203,22 @@ int sr_blend_plan_create(sr_ctx *ctx, const sr_tile_rect *h_tiles, int n, int cn
         // ---- marched zones and what is left for the regular blocks -----------------------------------------------------
         std::vector<MarchItem> mitems[MARCH_NT + 1];
         std::vector<int> reg_list;
-        plan_march(P, nbx_r, nby_r, mitems, reg_list);
+        std::vector<unsigned> cover;
+        plan_march(P, nbx_r, nby_r, mitems, reg_list, cover);
+        {
+            bool any_march = false;
+            for (int k = 1; k <= MARCH_NT; ++k) any_march = any_march || !mitems[k].empty();
+            if (any_march && (P->cn == 3 || P->cn == 1)) {
+                std::vector<RectItem> rects;
+                std::vector<int> rcand;
+                plan_rects(P, nbx_r, cover, rects, rcand);
+                P->n_rects = (long long)rects.size();
+                if ((e = hipMalloc((void **)&P->d_rects, sizeof(RectItem) * std::max<size_t>(rects.size(), 1))) != hipSuccess) return fail(e, "rectangle items");
+                if (!rects.empty() && (e = hipMemcpy(P->d_rects, rects.data(), sizeof(RectItem) * rects.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload");
+                if ((e = hipMalloc((void **)&P->d_rect_cand, sizeof(int) * std::max<size_t>(rcand.size(), 1))) != hipSuccess) return fail(e, "rectangle candidates");
+                if (!rcand.empty() && (e = hipMemcpy(P->d_rect_cand, rcand.data(), sizeof(int) * rcand.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload");
+            }
+        }
         {
             std::vector<int> all(nblk * 9, 0);
             for (size_t b = 0; b < nblk; ++b) all[b * 9] = (int)b;
@@ -4317,12 +4542,26 @@ static int blend_gather(sr_blend_plan *P, bool lap, int dtype, void *const *h_d_
             const long long n_reg = marched ? P->n_freg : P->n_freg_all;
             const int *reg_list = marched ? P->d_freg_list : P->d_freg_all;
             ProfScope ps3(ctx, "gather_rest");
+            // beside a march the remainder runs as rectangles of cells (k_final_rect: every cell finished in one visit, no edge
+            // blocks); SR_RECT=0 restores the masked 128 x 16 blocks + edge blocks (A/B runs; identical bytes)
+            static const bool rect_on = !(std::getenv("SR_RECT") && std::getenv("SR_RECT")[0] == '0');
+            const bool use_rects = marched && rect_on && P->d_rects != nullptr;
+            if (use_rects && P->n_rects > 0) {
+                if (P->cn == 3)
+                    hipLaunchKernelGGL((k_final_rect<3>), dim3((unsigned)P->n_rects), dim3(FU_THREADS), 0, ms[2], P->d_fdesc, P->d_rects,
+                                       P->d_rect_cand, P->d_arena, P->d_luts, d_canvas, (long long)canvas_stride, d_canvas_f32, P->canvas_w,
+                                       P->row_begin, P->row_end);
+                else
+                    hipLaunchKernelGGL((k_final_rect<1>), dim3((unsigned)P->n_rects), dim3(FU_THREADS), 0, ms[2], P->d_fdesc, P->d_rects,
+                                       P->d_rect_cand, P->d_arena, P->d_luts, d_canvas, (long long)canvas_stride, d_canvas_f32, P->canvas_w,
+                                       P->row_begin, P->row_end);
+            }
             dim3 grid((unsigned)std::max<long long>(n_edge + n_reg, 1)), blk1(FU_THREADS);
 #define LAUNCH_FUSED(DT, CNV)                                                                                          \
     hipLaunchKernelGGL((k_final_fused<DT, CNV>), grid, blk1, 0, ms[2], P->d_fdesc, P->d_fcand_off, P->d_fcand_idx,  \
                        P->d_fedge_blocks, P->d_fedge_cand, n_edge, nbx_r, reg_list, P->d_arena, P->d_luts, d_canvas,   \
                        (long long)canvas_stride, d_canvas_f32, P->canvas_w, P->row_begin, P->row_end)
-            if (n_edge + n_reg > 0) {
+            if (!use_rects && n_edge + n_reg > 0) {
                 if (P->cn == 3) { if (dtype == SR_U8) LAUNCH_FUSED(SRC_U8, 3); else LAUNCH_FUSED(SRC_F32, 3); }
                 else            { if (dtype == SR_U8) LAUNCH_FUSED(SRC_U8, 1); else LAUNCH_FUSED(SRC_F32, 1); }
             }
