@@ -3207,7 +3207,7 @@ static void plan_march(const sr_blend_plan *P, int nbx_r, int nby_r, std::vector
     const int CPB = FU_BH / 2;                                 // cell rows per regular block
     cover.assign((size_t)nbx_r * nby_r * CPB, 0u);                         // [cell row][block column]: cell column bits (1 = marched)
     // the marched kernels address the arena and a tile's pixels with 32-bit byte offsets (buffer instructions)
-    bool fits32 = P->arena_floats * sizeof(float) < 0xFFFF0000ull && (unsigned long long)cw * P->cn * 4ull * (2 * MARCH_SEG + 2) < 0xFFFF0000ull;
+    bool fits32 = P->arena_floats * sizeof(float) < 0xFFFF0000ull && (unsigned long long)cw * P->cn * 4ull * (2 * 64 + 2) < 0xFFFF0000ull;
     for (int t = 0; t < n && fits32; ++t) fits32 = (unsigned long long)P->tiles[t].h * P->tiles[t].w * P->cn * 4ull < 0x7FFF0000ull;
     // The march is four launches of long work items: it wins on a big canvas (200 MP: 1.12 against 1.22 ms for the block kernel
     // alone) and loses on a small one, where every launch is a few short items deep -- a rank's strip of a world of 4 / 8:
@@ -3311,25 +3311,44 @@ static void plan_march(const sr_blend_plan *P, int nbx_r, int nby_r, std::vector
         }
         for (int nt = 1; nt <= MARCH_NT; ++nt) {
             if (!steps_of[nt]) continue;
-            const long long want_items = (long long)P->ctx->num_cu * 8 / nt * 6;           // six rounds at two waves per SIMD
-            int seg = (int)std::min<long long>(MARCH_SEG, std::max<long long>(8, steps_of[nt] / want_items));
+            // Rounds per list, measured (profiles/r04_e_gather_sweep.txt): four for the 1-tile list, three for the 2-tile list, two
+            // for the short 3- / 4-tile lists (an item's warm-up is ~2.5 steps: at six rounds the 4-tile list was cut into 8-step
+            // items); the tapered end of a list (below) is what makes long items affordable.
+            // SR_MARCH_ROUNDS="r1,r2,r4" / SR_MARCH_SEG_MAX: A/B runs.
+            double rounds = nt >= 3 ? MARCH_ROUNDS_N : (nt == 2 ? MARCH_ROUNDS_2 : MARCH_ROUNDS);
+            if (const char *e_r = std::getenv("SR_MARCH_ROUNDS")) {
+                double r[3] = {0, 0, 0};
+                const int got = sscanf(e_r, "%lf,%lf,%lf", &r[0], &r[1], &r[2]);
+                const int k = nt == 1 ? 0 : (nt == 2 ? 1 : 2);
+                if (got >= 1 && r[std::min(k, got - 1)] > 0) rounds = r[std::min(k, got - 1)];
+            }
+            const char *e_s = std::getenv("SR_MARCH_SEG_MAX");
+            const int seg_max = e_s && atoi(e_s) >= 8 ? std::min(atoi(e_s), 64) : MARCH_SEG;
+            const long long want_items = std::max<long long>((long long)((double)(P->ctx->num_cu * 8 / nt) * rounds), 1);   // rounds at two waves per SIMD
+            int seg = (int)std::min<long long>(seg_max, std::max<long long>(8, steps_of[nt] / want_items));
             seg = seg / 2 * 2;
             // The items of a list run in list order, a few rounds of them: the last round leaves the GPU emptier and emptier
             // while its long items finish (half an item's duration per launch, ~30 us of march1's 300).  So the list ends
             // with short items: the last `tail` strip-steps (about one round of full-length items) are cut into segments of
             // half the length, the last quarter of those into the shortest ones (8 steps: an item's warm-up is ~2).
             // SR_MARCH_TAIL=0: uniform segments (A/B runs).  Which segment a canvas row falls into changes no value.
-            static const bool taper = !(std::getenv("SR_MARCH_TAIL") && std::getenv("SR_MARCH_TAIL")[0] == '0');
+            static const int taper = std::getenv("SR_MARCH_TAIL") ? atoi(std::getenv("SR_MARCH_TAIL")) : 1;
             const long long slots = std::max<long long>((long long)P->ctx->num_cu * 8 / nt, 1);
-            const long long tail = taper && seg > 8 ? std::min<long long>(slots * seg, steps_of[nt] / 3) : 0;
+            const long long tail = taper && seg > 8 ? std::min<long long>(slots * seg * (taper == 3 ? 2 : 1), steps_of[nt] / (taper == 3 ? 2 : 3)) : 0;
             long long done = 0;
             for (const Strip &st : strips) {
                 if (st.nt != nt) continue;
                 for (int sy = st.ya; sy < st.ye;) {
                     const long long left = steps_of[nt] - done;
                     int sg = seg;
-                    if (left <= tail / 4) sg = 8;
-                    else if (left <= tail) sg = std::max(8, seg / 4 * 2);
+                    if (taper == 2) {                                     // (A/B) three levels: 1/2, 1/4, shortest
+                        if (left <= tail / 8) sg = 8;
+                        else if (left <= tail / 2) sg = std::max(8, seg / 8 * 2);
+                        else if (left <= tail) sg = std::max(8, seg / 4 * 2);
+                    } else {
+                        if (left <= tail / 4) sg = 8;
+                        else if (left <= tail) sg = std::max(8, seg / 4 * 2);
+                    }
                     MarchItem it;
                     memset(&it, 0, sizeof(it));
                     it.x0 = 4 * (st.ca - 1);
@@ -3382,8 +3401,11 @@ static void plan_rects(const sr_blend_plan *P, int nbx_r, const std::vector<unsi
 {
     const int rows = P->row_end - P->row_begin, cw = P->canvas_w;
     const int ncxp = (cw + 3) / 4, ncyp = (rows + 1) / 2;
-    auto hmax = [](int w) {
-        int h = 256 / w;
+    const char *e_cells = std::getenv("SR_RECT_CELLS");                   // A/B runs: most cells per rectangle (<= 256 threads)
+    const int max_cells = e_cells && atoi(e_cells) >= 32 ? std::min(atoi(e_cells), 256) : 256;
+    const bool colmajor_on = !(std::getenv("SR_RECT_COLMAJOR") && std::getenv("SR_RECT_COLMAJOR")[0] == '0');
+    auto hmax = [max_cells](int w) {
+        int h = std::max(max_cells / w, 1);
         while (h > 1 && rect_rows(h) * rect_lp(w) > FU_PLANE) --h;
         return h;
     };
@@ -3404,7 +3426,7 @@ static void plan_rects(const sr_blend_plan *P, int nbx_r, const std::vector<unsi
         }
         it.ncand = (int)rcand.size() - it.cand;
         it.lp = rect_lp(it.w);
-        it.colmajor = it.h > it.w ? 1 : 0;
+        it.colmajor = (colmajor_on && it.h > it.w) ? 1 : 0;
         rects.push_back(it);
     };
     std::vector<std::pair<int, int>> segs;
