@@ -3404,9 +3404,12 @@ static void plan_rects(const sr_blend_plan *P, int nbx_r, const std::vector<unsi
     const char *e_cells = std::getenv("SR_RECT_CELLS");                   // A/B runs: most cells per rectangle (<= 256 threads)
     const int max_cells = e_cells && atoi(e_cells) >= 32 ? std::min(atoi(e_cells), 256) : 256;
     const bool colmajor_on = !(std::getenv("SR_RECT_COLMAJOR") && std::getenv("SR_RECT_COLMAJOR")[0] == '0');
-    auto hmax = [max_cells](int w) {
+    // window pitch: two pixel pairs more than needed, so that consecutive rows start 36 (not 32) dwords apart for a band 5 cells
+    // wide -- column-major lanes read the same columns of consecutive rows (SR_RECT_PAD=0: the bare pitch, A/B runs)
+    const int pad = (std::getenv("SR_RECT_PAD") && std::getenv("SR_RECT_PAD")[0] == '0') ? 0 : 2;
+    auto hmax = [max_cells, pad](int w) {
         int h = std::max(max_cells / w, 1);
-        while (h > 1 && rect_rows(h) * rect_lp(w) > FU_PLANE) --h;
+        while (h > 1 && rect_rows(h) * (rect_lp(w) + pad) > FU_PLANE) --h;
         return h;
     };
     struct Open { int ya, h; };
@@ -3425,7 +3428,7 @@ static void plan_rects(const sr_blend_plan *P, int nbx_r, const std::vector<unsi
             if (T.x < bx1 && (long long)T.x + T.w > bx0 && T.y < by1 && (long long)T.y + T.h > by0) rcand.push_back(t);
         }
         it.ncand = (int)rcand.size() - it.cand;
-        it.lp = rect_lp(it.w);
+        it.lp = rect_lp(it.w) + pad;
         it.colmajor = (colmajor_on && it.h > it.w) ? 1 : 0;
         rects.push_back(it);
     };

@@ -18,15 +18,9 @@ except Exception as e:
 P
 }
 for r in $(seq $REPS); do
-  run base_4_3_2_seg64  SR_DUMMY=1
-  run taper2            SR_MARCH_TAIL=2
-  run taper3            SR_MARCH_TAIL=3
-  run r_4_2.5_2         SR_MARCH_ROUNDS=4,2.5,2
-  run r_4_3.5_2         SR_MARCH_ROUNDS=4,3.5,2
-  run r_4.5_3_2         SR_MARCH_ROUNDS=4.5,3,2
-  run r_3.5_3_2         SR_MARCH_ROUNDS=3.5,3,2
-  run t2_r_3_2.5_1.5    SR_MARCH_TAIL=2 SR_MARCH_ROUNDS=3,2.5,1.5
-  run t3_r_3_2.5_1.5    SR_MARCH_TAIL=3 SR_MARCH_ROUNDS=3,2.5,1.5
-  run old_6_6_6_seg32   SR_MARCH_ROUNDS=6,6,6 SR_MARCH_SEG_MAX=32
+  run base_pad2         SR_DUMMY=1
+  run nopad             SR_RECT_PAD=0
+  run pad_rowmajor      SR_RECT_COLMAJOR=0
+  run pad_rect128       SR_RECT_CELLS=128
 done
 sort -s -k1,1 $OUT
