@@ -90,7 +90,7 @@ def algorithmic_bytes(geo, fused: bool = None) -> dict:
 ROCPROF_PREFIXES = {"tile_extract": ["k_tile_extract"], "down_l0": ["k_down_march<0,", "k_down2_march<"],
                     "down_l1p": ["k_down_march<2,", "k_down2_cols"],
                     "up_level": ["k_up_level_blk<"],
-                    "final_gather": ["k_final_fast<", "k_final_fused<", "k_final_march1<", "k_final_marchn<", "k_final_marchp<"],
+                    "final_gather": ["k_final_fast<", "k_final_fused<", "k_final_march1<", "k_final_marchn<", "k_final_marchp<", "k_final_rect<"],
                     "assess_all": ["k_assess_march<"]}
 BLEND_FAMILIES = ("down_l0", "down_l1p", "up_level", "final_gather")
 # VALU model of the fused assessment: per pixel (= per thread and row) the march issues ~223 VALU instructions
@@ -513,8 +513,9 @@ def run_workload(args, workload: str, steps: int, warmup: int, detailed: bool, d
                                  "GBps": None if b is None or per_step_ms <= 0 else round(b * share / 1e9 / (per_step_ms / 1e3), 1)}
             if parts and "final_gather" in kernels:
                 kernels["final_gather"]["parts_ms"] = parts
-                kernels["final_gather"]["parts_note"] = ("march<N>: column-marching kernels over the zones covered by N tiles; rest: the "
-                                                         "block kernel (border cells and what no march item takes)")
+                kernels["final_gather"]["parts_note"] = ("march<N>: column-marching kernels over the zones covered by N tiles; rest: what "
+                                                         "no march item takes (bands along the tile edges), as rectangles of cells "
+                                                         "(k_final_rect; the block kernel where nothing is marched)")
             roofline = None
             traffic = measured_traffic() if (world == 1 and workload == "200MP") else {}
             cands = [(v["ms_per_step"], k) for k, v in kernels.items() if v["alg_GB"] is not None]

@@ -28,6 +28,22 @@
 
 #include "sr_ctx.h"
 
+// Wave priority of the chain's kernels beside the assessment (A/B builds: -DSR_CHAIN_PRIO=1..3 for the small launches --
+// pyramid levels 2..5 down and up, the level-2 border columns -- -DSR_CHAIN_PRIO_BIG for tile extract and the level-1 + 2 march).
+// Measured and rejected (profiles/r04_e_chain_prio.txt): the step is 3.15-3.23 ms at every setting -- the small launches are
+// slow beside the assessment because ONE of their waves fits a SIMD next to its three (104 free registers), not because
+// they lose the issue arbitration.
+#ifdef SR_CHAIN_PRIO
+#define SR_CHAIN_SETPRIO() __builtin_amdgcn_s_setprio(SR_CHAIN_PRIO)
+#else
+#define SR_CHAIN_SETPRIO() ((void)0)
+#endif
+#ifdef SR_CHAIN_PRIO_BIG
+#define SR_CHAIN_SETPRIO_BIG() __builtin_amdgcn_s_setprio(SR_CHAIN_PRIO_BIG)
+#else
+#define SR_CHAIN_SETPRIO_BIG() ((void)0)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // context (struct, Guard, ProfScope: sr_ctx.h)
 // ---------------------------------------------------------------------------------------------
@@ -405,6 +421,7 @@ __global__ __launch_bounds__(256) void k_down_march(const TileDev *__restrict__ 
                                                     int lvl, int seg_rows, int march_blocks, float *__restrict__ arena,
                                                     const float *__restrict__ luts, int skip_down2)
 {
+    SR_CHAIN_SETPRIO();
     const TileDev &T = tiles[blockIdx.z];
     if (lvl + 1 >= T.nl) return;
     if (skip_down2 && down2_takes(T)) return;                       // levels 1 and 2 of this tile come from k_down2_march
@@ -1055,6 +1072,7 @@ __device__ __forceinline__ void up_level_thread(const TileDev &T, int lvl, float
 template <int CN>
 __global__ __launch_bounds__(256) void k_up_level_blk(const TileDev *__restrict__ tiles, int lvl, float *__restrict__ arena)
 {
+    SR_CHAIN_SETPRIO();
     const TileDev &T = tiles[blockIdx.z];
     if (lvl >= T.nl) return;
     const int w = T.W[lvl], h = T.H[lvl], p = T.P[lvl];
@@ -1985,6 +2003,7 @@ struct ExtractDesc {
 __global__ __launch_bounds__(256) void k_tile_extract(const unsigned char *__restrict__ img, long long istride,
                                                       int cn, const ExtractDesc *__restrict__ descs, int pad_mode)
 {
+    SR_CHAIN_SETPRIO_BIG();
     const ExtractDesc D = descs[blockIdx.z];
     const int r = blockIdx.y * 4 + threadIdx.y;
     const long long b0 = ((long long)blockIdx.x * 64 + threadIdx.x) * 16;
