@@ -4329,6 +4329,9 @@ static int blend_pyramids(sr_blend_plan *P, int dtype, void *const *h_d_tiles, c
     const int rows = P->row_end - P->row_begin;
     if (rows <= 0 || P->max_nl <= 1) return SR_OK;
     dim3 block(64, 4);
+    // TIMING PROBE ONLY (wrong pixels): leaves out the small launches of the chain -- level-2 border columns, levels 2 -> 5 down,
+    // the collapse 5 -> 2 -- to see what their stretched time beside the assessment costs the image stream
+    static const bool probe_skip_small = std::getenv("SR_PROBE_SKIP_SMALL") != nullptr;
     if (first && !P->weights_ready) {
         // weight pyramids: level 0 analytic (LUT) -> 1, then planar chain.  They depend only on the tile shapes and
         // the row windows, both fixed per plan: built by the first blend, kept in the arena for every later one.
@@ -4438,13 +4441,14 @@ static int blend_pyramids(sr_blend_plan *P, int dtype, void *const *h_d_tiles, c
                 dim3 grid2(items + (probe_nb ? 0 : (max_take_h1 + 3) / 4), 1, n_idx);
                 hipLaunchKernelGGL((k_down2_march<3>), grid2, dim3(64), 0, ctx->stream, d_tiles, d_srcs, seg2, items, P->d_arena,
                                    (unsigned)(P->arena_floats * sizeof(float)), P->d_arena, P->d_luts);
-            } else {
+            } else if (!probe_skip_small) {
                 dim3 grid2((max_take_cols + 255) / 256, 1, n_idx);
                 hipLaunchKernelGGL(k_down2_cols, grid2, dim3(256), 0, ctx->stream, d_tiles, P->d_arena);
             }
             if (n_take == n_idx) continue;
             skip2 = 1;
         }
+        if (blk && probe_skip_small && i >= 2) continue;
         if (blk) {
             int max_cells = 0, seg_rows = 2;
             for (int cand = 32; cand >= 2; cand /= 2) {       // longest segments that still give ~8 blocks per CU;
@@ -4487,7 +4491,7 @@ static int blend_pyramids(sr_blend_plan *P, int dtype, void *const *h_d_tiles, c
     if (rc) return rc;
     // collapse chain: levels max_nl-1 .. 1 (.. 2 when the gather is fused: it builds R_1 itself, in LDS)
     for (int i = max_nl - 1; i >= (P->fused ? 2 : 1); --i) {
-        if (max_r[i] <= 0) continue;
+        if (max_r[i] <= 0 || probe_skip_small) continue;
         ProfScope ps(ctx, "up_level");
         if (P->cn == 3 || P->cn == 1) {
             dim3 grid((max_w[i] + 255) / 256, (max_r[i] + 7) / 8, n_idx);

@@ -18,9 +18,7 @@ except Exception as e:
 P
 }
 for r in $(seq $REPS); do
-  run base_pad2         SR_DUMMY=1
-  run nopad             SR_RECT_PAD=0
-  run pad_rowmajor      SR_RECT_COLMAJOR=0
-  run pad_rect128       SR_RECT_CELLS=128
+  run base              SR_DUMMY=1
+  run probe_skip_small  SR_PROBE_SKIP_SMALL=1
 done
 sort -s -k1,1 $OUT
