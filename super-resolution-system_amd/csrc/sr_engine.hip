@@ -3351,7 +3351,7 @@ static void plan_march(const sr_blend_plan *P, int nbx_r, int nby_r, std::vector
             // with short items: the last `tail` strip-steps (about one round of full-length items) are cut into segments of
             // half the length, the last quarter of those into the shortest ones (8 steps: an item's warm-up is ~2).
             // SR_MARCH_TAIL=0: uniform segments (A/B runs).  Which segment a canvas row falls into changes no value.
-            static const int taper = std::getenv("SR_MARCH_TAIL") ? atoi(std::getenv("SR_MARCH_TAIL")) : 1;
+            const int taper = std::getenv("SR_MARCH_TAIL") ? atoi(std::getenv("SR_MARCH_TAIL")) : 1;   // read per plan
             const long long slots = std::max<long long>((long long)P->ctx->num_cu * 8 / nt, 1);
             const long long tail = taper && seg > 8 ? std::min<long long>(slots * seg * (taper == 3 ? 2 : 1), steps_of[nt] / (taper == 3 ? 2 : 3)) : 0;
             long long done = 0;
@@ -4592,7 +4592,7 @@ static int blend_gather(sr_blend_plan *P, bool lap, int dtype, void *const *h_d_
             ProfScope ps3(ctx, "gather_rest");
             // beside a march the remainder runs as rectangles of cells (k_final_rect: every cell finished in one visit, no edge
             // blocks); SR_RECT=0 restores the masked 128 x 16 blocks + edge blocks (A/B runs; identical bytes)
-            static const bool rect_on = !(std::getenv("SR_RECT") && std::getenv("SR_RECT")[0] == '0');
+            const bool rect_on = !(std::getenv("SR_RECT") && std::getenv("SR_RECT")[0] == '0');     // read per call: the tests switch it
             const bool use_rects = marched && rect_on && P->d_rects != nullptr;
             if (use_rects && P->n_rects > 0) {
                 if (P->cn == 3)

@@ -23,6 +23,9 @@ def run(cases: int = 200, seed: int = 1) -> int:
     for it in range(cases):
         # both forms of the canvas gather: the march (forced: the default takes it from 90 MP of canvas up) and the block kernel
         os.environ["SR_MARCH"] = "2" if it % 3 else "1"
+        # the remainder of a marched gather: rectangles of cells (default; every 7th case small ones) or the masked blocks + edge blocks
+        os.environ["SR_RECT"] = "0" if it % 5 == 4 else "1"
+        os.environ["SR_RECT_CELLS"] = "48" if it % 7 == 3 else "256"
         n = int(rng.integers(1, 7))
         cn = int(rng.choice([1, 3]))
         levels = int(rng.integers(1, 7))

@@ -52,10 +52,17 @@ GRIDS = [
 ]
 
 
-@pytest.mark.parametrize("march", ["2", "1"])          # the marched gather forced / the default of a small canvas: the block kernel
+# the marched gather forced (its remainder as rectangles of cells: k_final_rect) / the same with the remainder through the masked
+# blocks + edge blocks / with uniform item segments cut for six rounds / the default of a small canvas: the block kernel alone
+MARCH_FORMS = [("2", {}), ("2", {"SR_RECT": "0"}), ("2", {"SR_MARCH_TAIL": "0", "SR_MARCH_ROUNDS": "6,6,6", "SR_RECT_CELLS": "64"}), ("1", {})]
+
+
+@pytest.mark.parametrize("march,env", MARCH_FORMS)
 @pytest.mark.parametrize("th,tw,rows,cols,ov,levels,wt", GRIDS)
-def test_laplacian_fusion_grid(ctx, rng, th, tw, rows, cols, ov, levels, wt, march, monkeypatch):
+def test_laplacian_fusion_grid(ctx, rng, th, tw, rows, cols, ov, levels, wt, march, env, monkeypatch):
     monkeypatch.setenv("SR_MARCH", march)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     tiles = _tiles(rng, rows * cols, th, tw)
     pos = [((i // cols) * (th - ov), (i % cols) * (tw - ov)) for i in range(rows * cols)]
     shape = (rows * th - (rows - 1) * ov, cols * tw - (cols - 1) * ov)
