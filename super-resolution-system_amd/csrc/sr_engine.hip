@@ -1836,8 +1836,11 @@ static_assert(sizeof(RectItem) == 32, "RectItem layout");
 static inline int rect_lp(int w) { return 4 * ((2 * w + 4) / 4) + 4; }
 static inline int rect_rows(int h) { return 2 * ((h + 2) / 2) + 2; }
 
+#ifndef FR_WAVES
+#define FR_WAVES FU_WAVES     /* waves per SIMD the register allocation of k_final_rect is held to */
+#endif
 template <int CN>
-__global__ __launch_bounds__(FU_THREADS, FU_WAVES) void k_final_rect(const FinalDesc *__restrict__ descs, const RectItem *__restrict__ rects,
+__global__ __launch_bounds__(FU_THREADS, FR_WAVES) void k_final_rect(const FinalDesc *__restrict__ descs, const RectItem *__restrict__ rects,
                                                         const int *__restrict__ rect_cand, const float *__restrict__ arena,
                                                         const float *__restrict__ luts, unsigned char *__restrict__ canvas,
                                                         long long cstride, float *__restrict__ canvas_f32, int cw, int row_begin,
@@ -3452,6 +3455,16 @@ static void plan_rects(const sr_blend_plan *P, int nbx_r, const std::vector<unsi
         rects.push_back(it);
     };
     std::vector<std::pair<int, int>> segs;
+    std::map<std::pair<int, int>, std::pair<int, int>> wide;      // wide run (first cell, end) -> (piece width, last row seen)
+    const bool wide_on = !(std::getenv("SR_RECT_WIDE") && std::getenv("SR_RECT_WIDE")[0] == '0');
+    auto unmarched = [&](int cy, int cx) { return !((cover[(size_t)cy * nbx_r + (cx >> 5)] >> (cx & 31)) & 1u); };
+    auto run_is = [&](int cy, int xa, int xe) {                   // row cy holds exactly the run [xa, xe) of unmarched cells
+        if (xa > 0 && unmarched(cy, xa - 1)) return false;
+        if (xe < ncxp && unmarched(cy, xe)) return false;
+        for (int c = xa; c < xe; ++c)
+            if (!unmarched(cy, c)) return false;
+        return true;
+    };
     for (int cy = 0; cy < ncyp; ++cy) {
         segs.clear();
         const unsigned *row = cover.data() + (size_t)cy * nbx_r;
@@ -3462,12 +3475,31 @@ static void plan_rects(const sr_blend_plan *P, int nbx_r, const std::vector<unsi
             int xe = cx;
             while (xe < ncxp && !((row[xe >> 5] >> (xe & 31)) & 1u)) ++xe;
             if (xe - cx <= 8) segs.emplace_back(cx, xe);
-            else
+            else {
+                // a wide run: pieces as wide as the band's height allows (a band 3-4 cell rows high along a horizontal tile
+                // edge: 60 cells x 4 rows instead of 32 x 4 -- fewer, fuller items); the width is chosen where the band starts
+                // and kept for its rows, so that the pieces of consecutive rows stack
+                int pw = 32;
+                auto rec = wide.find({cx, xe});
+                if (rec != wide.end() && rec->second.second == cy - 1) {
+                    pw = rec->second.first;
+                    rec->second.second = cy;
+                } else {
+                    int H = 1;
+                    while (H < 9 && cy + H < ncyp && run_is(cy + H, cx, xe)) ++H;
+                    if (wide_on && H <= 8) {
+                        pw = std::min(64, 256 / H) / 4 * 4;
+                        while (pw > 32 && rect_rows(H) * (rect_lp(pw) + pad) > FU_PLANE) pw -= 4;
+                        pw = std::max(pw, 32);
+                    }
+                    wide[{cx, xe}] = {pw, cy};
+                }
                 for (int a = cx; a < xe;) {
-                    const int b = std::min(xe, (a / 32 + 1) * 32);
+                    const int b = std::min(xe, (a / pw + 1) * pw);
                     segs.emplace_back(a, b);
                     a = b;
                 }
+            }
             cx = xe;
         }
         std::map<std::pair<int, int>, Open> next;

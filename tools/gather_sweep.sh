@@ -18,7 +18,7 @@ except Exception as e:
 P
 }
 for r in $(seq $REPS); do
-  run base              SR_DUMMY=1
-  run probe_skip_small  SR_PROBE_SKIP_SMALL=1
+  run base_wide         SR_DUMMY=1
+  run narrow32          SR_RECT_WIDE=0
 done
 sort -s -k1,1 $OUT
